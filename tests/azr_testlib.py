@@ -1,0 +1,248 @@
+"""ctypes loaders shared by the tests (TEST INFRASTRUCTURE).
+
+Three libraries:
+  * oracle/libazr_oracle.so     — the plain-C CPU restatement (checker)
+  * oracle/_ref/libazr_ref.so   — the real reference's TF-free units, built in the build container only
+  * alphazero-risk_amd/csrc/libazr_hip.so — the product (HIP, C-ABI of include/azr.h)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "libazr_oracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libazr_ref.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+u8p = C.POINTER(C.c_uint8)
+u64p = C.POINTER(C.c_uint64)
+f32p = C.POINTER(C.c_float)
+
+
+class OrcSettings(C.Structure):
+    _fields_ = [("allow_yield", C.c_int), ("limit_reinforcement", C.c_int), ("limit_attack", C.c_int),
+                ("max_game_rounds", C.c_int), ("min_unit_move", C.c_int), ("mcts_simulations", C.c_int),
+                ("hp_exploration", C.c_float), ("dir_noise_value", C.c_float), ("dir_noise_epsi", C.c_float),
+                ("temperature_threshold", C.c_int)]
+
+
+class OrcPlayer(C.Structure):
+    _fields_ = [("owned", C.c_uint64), ("owned_army", C.c_uint64), ("owned_full", C.c_uint64),
+                ("attack", C.c_uint64), ("attack_army", C.c_uint64), ("total_army", C.c_int16), ("cards", C.c_uint8)]
+
+
+class OrcState(C.Structure):
+    _fields_ = [("army", C.c_uint8 * 42), ("owner", C.c_uint8 * 42), ("ps", OrcPlayer * 2),
+                ("round", C.c_uint16), ("cur", C.c_int8), ("card_sets", C.c_uint8), ("reinf", C.c_uint8),
+                ("phase", C.c_uint8), ("mob_from", C.c_uint8), ("mob_to", C.c_uint8), ("allow_draw", C.c_uint8),
+                ("attacks", C.c_uint8), ("drawn", C.c_uint16)]
+
+
+class OrcRng(C.Structure):
+    _fields_ = [("x", C.c_uint32)]
+
+
+class OrcNet(C.Structure):
+    _fields_ = [("blocks", C.c_int), ("flat", f32p)]
+
+
+EVAL_FN = C.CFUNCTYPE(None, C.c_void_p, u8p, f32p, f32p)
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+
+
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
+                os.path.join(ROOT, "oracle", "azr_oracle.c")):
+            build_oracle()
+        L = C.CDLL(ORACLE_SO)
+        L.orc_rng_next.restype = C.c_uint32
+        L.orc_rng_float.restype = C.c_float
+        L.orc_random_mask.restype = C.c_uint64
+        L.orc_random_mask.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_neighbour_mask.restype = C.c_uint64
+        L.orc_continent_mask.restype = C.c_uint64
+        L.orc_valid_moves.restype = C.c_uint64
+        L.orc_reinforcement_value.argtypes = [C.c_uint64]
+        L.orc_normalize.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_umap_order.argtypes = [C.c_uint64, C.c_void_p]
+        L.orc_net_param_count.restype = C.c_size_t
+        L.orc_net_init_random.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+        L.orc_mcts_create.restype = C.c_void_p
+        L.orc_mcts_destroy.argtypes = [C.c_void_p]
+        L.orc_mcts_clear.argtypes = [C.c_void_p]
+        L.orc_mcts_trim.argtypes = [C.c_void_p]
+        L.orc_mcts_node_count.argtypes = [C.c_void_p]
+        L.orc_mcts_simulate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_mcts_root_stats.argtypes = [C.c_void_p] * 6
+        L.orc_mcts_policy.argtypes = [C.c_void_p] * 3
+        L.orc_pick_highest.argtypes = [C.c_void_p]
+        L.orc_pick_random.argtypes = [C.c_void_p, C.c_void_p]
+        for f in ("orc_mcts_sim_count", "orc_mcts_eval_count", "orc_mcts_level_count"):
+            getattr(L, f).restype = C.c_uint64
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.orc_selfplay_game.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_play_random_game.argtypes = [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]
+        L.orc_net_forward_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_net_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _oracle = L
+    return _oracle
+
+
+_ref = None
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        L = C.CDLL(REF_SO)
+        L.ref_last_error.restype = C.c_char_p
+        L.ref_rng_float.restype = C.c_float
+        L.ref_rng_state.restype = C.c_uint32
+        L.ref_random_mask.restype = C.c_uint64
+        L.ref_random_mask.argtypes = [C.c_uint64]
+        L.ref_neighbour_mask.restype = C.c_uint64
+        L.ref_continent_mask.restype = C.c_uint64
+        L.ref_valid_moves.restype = C.c_uint64
+        L.ref_valid_moves.argtypes = [C.c_void_p]
+        L.ref_game_status.argtypes = [C.c_void_p]
+        L.ref_reinforcement_value.argtypes = [C.c_uint64]
+        L.ref_make_move.argtypes = [C.c_void_p, C.c_int]
+        L.ref_new_game.argtypes = [C.c_void_p]
+        L.ref_blank_state.argtypes = [C.c_void_p]
+        L.ref_encode.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_normalize.argtypes = [C.c_void_p, C.c_uint64]
+        L.ref_update_values.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.ref_invert_players.argtypes = [C.c_void_p]
+        L.ref_play_random_game.argtypes = [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]
+        _ref = L
+    return _ref
+
+
+def default_settings(**kw):
+    s = OrcSettings()
+    oracle().orc_default_settings(C.byref(s))
+    for k, v in kw.items():
+        setattr(s, k, v)
+    return s
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def orc_random_game(seed, cap=4096, cfg=None):
+    """returns dict(states[n,160], masks[n], moves[n], status, final[160])"""
+    L = oracle()
+    cfg = cfg or default_settings()
+    states = np.zeros((cap, 160), np.uint8)
+    masks = np.zeros(cap, np.uint64)
+    moves = np.zeros(cap, np.uint8)
+    final = np.zeros(160, np.uint8)
+    status = C.c_int(0)
+    n = L.orc_play_random_game(seed, cap, ptr(states), ptr(masks), ptr(moves), C.byref(status), ptr(final),
+                               C.byref(cfg))
+    return dict(states=states[:n].copy(), masks=masks[:n].copy(), moves=moves[:n].copy(), status=status.value,
+                final=final)
+
+
+def ref_random_game(seed, cap=4096):
+    L = ref()
+    states = np.zeros((cap, 160), np.uint8)
+    masks = np.zeros(cap, np.uint64)
+    moves = np.zeros(cap, np.uint8)
+    final = np.zeros(160, np.uint8)
+    status = C.c_int(0)
+    n = L.ref_play_random_game(seed, cap, ptr(states), ptr(masks), ptr(moves), C.byref(status), ptr(final))
+    return dict(states=states[:n].copy(), masks=masks[:n].copy(), moves=moves[:n].copy(), status=status.value,
+                final=final)
+
+
+# bytes of the 160-byte Data image that carry information (everything else is struct padding)
+def data_field_mask():
+    m = np.zeros(160, bool)
+    m[0:42] = True
+    for p in range(2):
+        b = 48 + 48 * p
+        for off in (0, 8, 16, 24, 32):
+            m[b + off:b + off + 6] = True
+        m[b + 38:b + 41] = True
+    m[144:156] = True
+    return m
+
+
+def make_net_flat(blocks, seed=20260002, perturb_bn=False):
+    """AZRW flat fp32 parameter vector (layout documented in oracle/azr_oracle.c and DESIGN.md)."""
+    L = oracle()
+    n = L.orc_net_param_count(blocks)
+    flat = np.zeros(n, np.float32)
+    L.orc_net_init_random(ptr(flat), blocks, seed)
+    if perturb_bn:
+        rng = np.random.default_rng(seed + 1)
+        for off, c in bn_offsets(blocks):
+            flat[off:off + c] = rng.uniform(0.5, 1.5, c)            # gamma
+            flat[off + c:off + 2 * c] = rng.uniform(-0.2, 0.2, c)   # beta
+            flat[off + 2 * c:off + 3 * c] = rng.uniform(-0.1, 0.1, c)  # mean
+            flat[off + 3 * c:off + 4 * c] = rng.uniform(0.5, 1.5, c)   # var
+        # biases
+        for off, c in bias_offsets(blocks):
+            flat[off:off + c] = rng.uniform(-0.1, 0.1, c)
+    return flat
+
+
+def _layout(blocks):
+    F = 256
+    off = 0
+    items = []
+
+    def add(name, n):
+        nonlocal off
+        items.append((name, off, n))
+        off += n
+
+    add("stem_w", 9 * 13 * F)
+    add("stem_bn", 28)
+    for b in range(blocks):
+        add(f"b{b}a_w", 9 * F * F)
+        add(f"b{b}a_bn", 4 * F)
+        add(f"b{b}b_w", 9 * F * F)
+        add(f"b{b}b_bn", 4 * F)
+    add("pi_w", F * 2)
+    add("pi_bn", 8)
+    add("pd_w", 84 * 43)
+    add("pd_b", 43)
+    add("v_w", F)
+    add("v_bn", 4)
+    add("v1_w", 42 * 256)
+    add("v1_b", 256)
+    add("v2_w", 256)
+    add("v2_b", 1)
+    return items, off
+
+
+def net_layout(blocks):
+    return _layout(blocks)[0]
+
+
+def bn_offsets(blocks):
+    return [(off, n // 4) for name, off, n in _layout(blocks)[0] if name.endswith("_bn")]
+
+
+def bias_offsets(blocks):
+    return [(off, n) for name, off, n in _layout(blocks)[0] if name.endswith("_b")]
