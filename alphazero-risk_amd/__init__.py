@@ -1,0 +1,8 @@
+"""alphazero-risk_amd — MI355X-native AlphaZero-Risk self-play hot path.
+
+The product is the HIP shared library `csrc/libazr_hip.so` behind the C-ABI of `include/azr.h`;
+this package is the thin ctypes binding used by tests, bench.py and the Python-side tooling.
+It fails loudly when the HIP library is missing (there is no CPU fallback).
+"""
+from .binding import Engine, Settings, Counters, build, lib_path, load_library, AzrError  # noqa: F401
+from .binding import NET_F32, NET_BF16, MOVES, STATE_BYTES, INPUT_BYTES, RECORD_BYTES  # noqa: F401

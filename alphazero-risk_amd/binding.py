@@ -1,0 +1,302 @@
+"""ctypes binding of include/azr.h (libazr_hip.so).  No compute happens in Python."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+NET_F32, NET_BF16 = 0, 1
+MOVES, STATE_BYTES, INPUT_BYTES, RECORD_BYTES = 43, 160, 88, 265
+
+
+class AzrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"azr error {code}: {msg}")
+        self.code = code
+
+
+class Settings(C.Structure):
+    """`azr_settings` — mirrors the reference's `class Settings` fields the hot path reads (src/settings.h:41-64)."""
+    _fields_ = [("device", C.c_int32), ("games", C.c_int32), ("blocks", C.c_int32), ("net_dtype", C.c_int32),
+                ("mcts_simulations", C.c_int32), ("allow_yield", C.c_int32), ("limit_reinforcement", C.c_int32),
+                ("limit_attack", C.c_int32), ("max_game_rounds", C.c_int32), ("min_unit_move", C.c_int32),
+                ("temperature_threshold", C.c_int32), ("hp_exploration", C.c_float), ("dir_noise_value", C.c_float),
+                ("dir_noise_epsi", C.c_float), ("node_capacity", C.c_int32), ("sample_capacity", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("simulations", "evaluations", "levels", "decisions", "games_finished",
+                                          "samples", "nodes_dropped", "errors")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def lib_path():
+    return os.path.join(CSRC, "libazr_hip.so")
+
+
+def build(jobs=3):
+    """Compile every HIP translation unit for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-j", str(jobs), "-C", CSRC])
+    return lib_path()
+
+
+_lib = None
+
+EXPORTS = [
+    "azr_default_settings", "azr_engine_create", "azr_engine_destroy", "azr_last_error", "azr_engine_games",
+    "azr_engine_new_games", "azr_engine_set_states", "azr_engine_get_states", "azr_engine_set_rng", "azr_engine_get_rng",
+    "azr_engine_valid_moves", "azr_engine_make_moves", "azr_engine_status", "azr_engine_encode",
+    "azr_nn_param_count", "azr_nn_init_random", "azr_nn_set_weights", "azr_nn_get_weights", "azr_nn_load", "azr_nn_save",
+    "azr_nn_predict", "azr_mcts_clear", "azr_mcts_trim", "azr_mcts_simulate", "azr_mcts_begin", "azr_mcts_leaves",
+    "azr_mcts_apply", "azr_mcts_root_stats", "azr_mcts_policy", "azr_mcts_pick", "azr_selfplay_start", "azr_selfplay_run",
+    "azr_selfplay_counters", "azr_samples_drain", "azr_samples_device_view", "azr_profile_last_run",
+    "azr_device_synchronize",
+]
+
+
+def load_library():
+    """dlopen libazr_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise FileNotFoundError(f"{p} missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                    "(the HIP path is the only path; there is no CPU fallback)")
+        L = C.CDLL(p)
+        L.azr_last_error.restype = C.c_char_p
+        L.azr_last_error.argtypes = [C.c_void_p]
+        L.azr_nn_param_count.restype = C.c_size_t
+        L.azr_nn_param_count.argtypes = [C.c_int]
+        L.azr_engine_create.argtypes = [C.c_void_p, C.c_void_p]
+        for name in EXPORTS:
+            f = getattr(L, name)
+            if f.argtypes is None and name not in ("azr_default_settings",):
+                pass
+        L.azr_nn_init_random.argtypes = [C.c_void_p, C.c_uint64]
+        L.azr_nn_set_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.azr_nn_get_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.azr_nn_load.argtypes = [C.c_void_p, C.c_char_p]
+        L.azr_nn_save.argtypes = [C.c_void_p, C.c_char_p]
+        L.azr_nn_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.azr_selfplay_start.argtypes = [C.c_void_p, C.c_uint32]
+        L.azr_selfplay_run.argtypes = [C.c_void_p, C.c_int]
+        L.azr_samples_drain.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.azr_samples_device_view.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.azr_mcts_pick.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.azr_mcts_leaves.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.azr_mcts_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.azr_mcts_root_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.azr_profile_last_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        for name in ("azr_engine_destroy", "azr_engine_games", "azr_mcts_clear", "azr_mcts_trim", "azr_mcts_simulate",
+                     "azr_mcts_begin", "azr_device_synchronize"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        for name in ("azr_engine_new_games", "azr_engine_set_states", "azr_engine_get_states", "azr_engine_set_rng",
+                     "azr_engine_get_rng", "azr_engine_valid_moves", "azr_engine_status", "azr_engine_encode",
+                     "azr_mcts_policy", "azr_selfplay_counters"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
+        L.azr_engine_make_moves.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One handle = one GPU = G concurrent games.  Method names follow the reference seams:
+    State / UtilityNN (rules), AlphaZeroNNId (net), AlphaZeroMCTS (search), trainer move loop (self-play)."""
+
+    def __init__(self, games, blocks=20, sims=32, dtype=NET_BF16, device=0, **kw):
+        self.L = load_library()
+        s = Settings()
+        self.L.azr_default_settings(C.byref(s))
+        s.device, s.games, s.blocks, s.mcts_simulations, s.net_dtype = device, games, blocks, sims, dtype
+        for k, v in kw.items():
+            if not hasattr(s, k):
+                raise TypeError(f"unknown setting {k}")
+            setattr(s, k, v)
+        self.settings = s
+        self.G = games
+        self.blocks = blocks
+        self.h = C.c_void_p()
+        rc = self.L.azr_engine_create(C.byref(s), C.byref(self.h))
+        if rc:
+            msg = self.L.azr_last_error(self.h).decode() if self.h else "create failed"
+            if self.h:
+                self.L.azr_engine_destroy(self.h)
+                self.h = None
+            raise AzrError(rc, msg)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.azr_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise AzrError(rc, self.L.azr_last_error(self.h).decode())
+
+    # ---- rules
+    def new_games(self, seeds):
+        seeds = np.ascontiguousarray(seeds, np.uint32)
+        assert seeds.shape == (self.G,)
+        self._chk(self.L.azr_engine_new_games(self.h, _p(seeds)))
+
+    def set_states(self, data160):
+        d = np.ascontiguousarray(data160, np.uint8)
+        assert d.shape == (self.G, 160)
+        self._chk(self.L.azr_engine_set_states(self.h, _p(d)))
+
+    def get_states(self):
+        d = np.zeros((self.G, 160), np.uint8)
+        self._chk(self.L.azr_engine_get_states(self.h, _p(d)))
+        return d
+
+    def set_rng(self, x):
+        x = np.ascontiguousarray(x, np.uint32)
+        assert x.shape == (self.G,)
+        self._chk(self.L.azr_engine_set_rng(self.h, _p(x)))
+
+    def get_rng(self):
+        x = np.zeros(self.G, np.uint32)
+        self._chk(self.L.azr_engine_get_rng(self.h, _p(x)))
+        return x
+
+    def valid_moves(self):
+        m = np.zeros(self.G, np.uint64)
+        self._chk(self.L.azr_engine_valid_moves(self.h, _p(m)))
+        return m
+
+    def make_moves(self, moves):
+        mv = np.ascontiguousarray(moves, np.uint8)
+        assert mv.shape == (self.G,)
+        rc = np.zeros(self.G, np.uint8)
+        self._chk(self.L.azr_engine_make_moves(self.h, _p(mv), _p(rc)))
+        return rc
+
+    def status(self):
+        s = np.zeros(self.G, np.int8)
+        self._chk(self.L.azr_engine_status(self.h, _p(s)))
+        return s
+
+    def encode(self):
+        e = np.zeros((self.G, 88), np.uint8)
+        self._chk(self.L.azr_engine_encode(self.h, _p(e)))
+        return e
+
+    # ---- net
+    def param_count(self):
+        return self.L.azr_nn_param_count(self.blocks)
+
+    def init_random(self, seed=20260002):
+        self._chk(self.L.azr_nn_init_random(self.h, seed))
+
+    def set_weights(self, flat):
+        f = np.ascontiguousarray(flat, np.float32)
+        self._chk(self.L.azr_nn_set_weights(self.h, _p(f), f.size))
+
+    def get_weights(self):
+        f = np.zeros(self.param_count(), np.float32)
+        self._chk(self.L.azr_nn_get_weights(self.h, _p(f), f.size))
+        return f
+
+    def save(self, path):
+        self._chk(self.L.azr_nn_save(self.h, path.encode()))
+
+    def load(self, path):
+        self._chk(self.L.azr_nn_load(self.h, path.encode()))
+
+    def predict(self, in88):
+        x = np.ascontiguousarray(in88, np.uint8)
+        n = x.shape[0]
+        assert x.shape == (n, 88)
+        pi = np.zeros((n, 43), np.float32)
+        v = np.zeros(n, np.float32)
+        self._chk(self.L.azr_nn_predict(self.h, _p(x), n, _p(pi), _p(v)))
+        return pi, v
+
+    # ---- search
+    def mcts_clear(self):
+        self._chk(self.L.azr_mcts_clear(self.h))
+
+    def mcts_trim(self):
+        self._chk(self.L.azr_mcts_trim(self.h))
+
+    def simulate(self):
+        self._chk(self.L.azr_mcts_simulate(self.h))
+
+    def mcts_begin(self):
+        self._chk(self.L.azr_mcts_begin(self.h))
+
+    def mcts_leaves(self):
+        x = np.zeros((self.G, 88), np.uint8)
+        need = np.zeros(self.G, np.uint8)
+        act = C.c_int(0)
+        self._chk(self.L.azr_mcts_leaves(self.h, _p(x), _p(need), C.byref(act)))
+        return x, need.astype(bool), act.value
+
+    def mcts_apply(self, pi, v):
+        pi = np.ascontiguousarray(pi, np.float32)
+        v = np.ascontiguousarray(v, np.float32)
+        assert pi.shape == (self.G, 43) and v.shape == (self.G,)
+        self._chk(self.L.azr_mcts_apply(self.h, _p(pi), _p(v)))
+
+    def root_stats(self):
+        n = np.zeros((self.G, 43), np.uint32)
+        q = np.zeros((self.G, 43), np.float32)
+        p = np.zeros((self.G, 43), np.float32)
+        self._chk(self.L.azr_mcts_root_stats(self.h, _p(n), _p(q), _p(p)))
+        return n, q, p
+
+    def policy(self):
+        pi = np.zeros((self.G, 43), np.float32)
+        self._chk(self.L.azr_mcts_policy(self.h, _p(pi)))
+        return pi
+
+    def pick(self, sample=False):
+        m = np.zeros(self.G, np.uint8)
+        self._chk(self.L.azr_mcts_pick(self.h, int(sample), _p(m)))
+        return m
+
+    # ---- self-play
+    def selfplay_start(self, base_seed=20260001):
+        self._chk(self.L.azr_selfplay_start(self.h, base_seed))
+
+    def selfplay_run(self, passes):
+        self._chk(self.L.azr_selfplay_run(self.h, passes))
+
+    def counters(self):
+        c = Counters()
+        self._chk(self.L.azr_selfplay_counters(self.h, C.byref(c)))
+        return c.as_dict()
+
+    def drain(self, cap=1 << 20):
+        buf = np.zeros((cap, RECORD_BYTES), np.uint8)
+        n = C.c_size_t(0)
+        self._chk(self.L.azr_samples_drain(self.h, _p(buf), cap, C.byref(n)))
+        return buf[:n.value].copy()
+
+    def samples_device_view(self):
+        ptr = C.c_void_p()
+        n = C.c_size_t(0)
+        self._chk(self.L.azr_samples_device_view(self.h, C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    def profile_last_run(self):
+        a, b, k = C.c_float(0), C.c_float(0), C.c_int(0)
+        self._chk(self.L.azr_profile_last_run(self.h, C.byref(a), C.byref(b), C.byref(k)))
+        return dict(net_ms=a.value, tree_ms=b.value, launches=k.value)
+
+    def synchronize(self):
+        self._chk(self.L.azr_device_synchronize(self.h))

@@ -1,0 +1,966 @@
+// azr_engine.hip — kernels and C-ABI (include/azr.h) of the batched Risk state-step + flattened MCTS.
+// One wavefront per game; grid = G workgroups of 64 threads.  gfx950 only.
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "azr_internal.hpp"
+
+using namespace azr;
+
+#define HIPCHK(h, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
+            return AZR_E_HIP;                                                                   \
+        }                                                                                       \
+    } while (0)
+
+// ================================================================================================
+// device helpers
+// ================================================================================================
+__device__ __forceinline__ Tree tree_of(const Dev& E, int g)
+{
+    Tree t;
+    t.C = E.C; t.H = E.H; t.DMAX = E.DMAX;
+    t.nodes = E.nodes + (size_t)g * E.C * NODE_BYTES;
+    t.touch = E.touch + (size_t)g * E.C;
+    t.nhash = E.nhash + (size_t)g * E.C;
+    t.table = E.table + (size_t)g * E.H;
+    t.freel = E.freel + (size_t)g * E.C;
+    t.path = E.path + (size_t)g * E.DMAX;
+    return t;
+}
+
+__device__ __forceinline__ void ctl_load(Ctl& c, const Ctl* src)
+{
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(src);
+    uint32_t w = p[lane_id() & 15u];
+    c.mode = rdl(w, 0); c.search_id = rdl(w, 1); c.sims_done = rdl(w, 2); c.pending = rdl(w, 3);
+    c.path_len = rdl(w, 4); c.nfree = rdl(w, 5); c.hiwater = rdl(w, 6); c.search_done = rdl(w, 7);
+    c.rng = rdl(w, 8); c.game_no = rdl(w, 9); c.nsamples = rdl(w, 10); c.status = (int32_t)rdl(w, 11);
+    c.error = rdl(w, 12); c.last_move = rdl(w, 13); c.decisions = rdl(w, 14); c.seed = rdl(w, 15);
+}
+__device__ __forceinline__ void ctl_store(const Ctl& c, Ctl* dst)
+{
+    uint32_t l = lane_id();
+    uint32_t w = 0;
+    w = l == 0 ? c.mode : w; w = l == 1 ? c.search_id : w; w = l == 2 ? c.sims_done : w; w = l == 3 ? c.pending : w;
+    w = l == 4 ? c.path_len : w; w = l == 5 ? c.nfree : w; w = l == 6 ? c.hiwater : w; w = l == 7 ? c.search_done : w;
+    w = l == 8 ? c.rng : w; w = l == 9 ? c.game_no : w; w = l == 10 ? c.nsamples : w; w = l == 11 ? (uint32_t)c.status : w;
+    w = l == 12 ? c.error : w; w = l == 13 ? c.last_move : w; w = l == 14 ? c.decisions : w; w = l == 15 ? c.seed : w;
+    if (l < 16) reinterpret_cast<uint32_t*>(dst)[l] = w;
+}
+
+// ================================================================================================
+// rules kernels (UtilityNN / State seams)
+// ================================================================================================
+__global__ __launch_bounds__(64) void k_new_games(Dev E, const uint32_t* seeds)
+{
+    const int g = blockIdx.x;
+    WS s;
+    ws_blank(s);
+    s.rng = rng_seed(rfl(seeds[g]));
+    new_game(s);
+    ws_store(s, E.state + (size_t)g * GREC);
+    if (lane_id() == 0) E.ctl[g].rng = s.rng;
+}
+
+__global__ __launch_bounds__(64) void k_valid_moves(Dev E, uint64_t* out)
+{
+    const int g = blockIdx.x;
+    WS s;
+    ws_load(s, E.state + (size_t)g * GREC);
+    uint64_t vm = valid_moves(s, E.rules);
+    if (lane_id() == 0) out[g] = vm;
+}
+
+__global__ __launch_bounds__(64) void k_make_moves(Dev E, const uint8_t* moves, uint8_t* rc)
+{
+    const int g = blockIdx.x;
+    const uint32_t mv = rfl(moves[g]);
+    if (mv == 255u) {
+        if (lane_id() == 0) rc[g] = 0;
+        return;
+    }
+    WS s;
+    ws_load(s, E.state + (size_t)g * GREC);
+    s.rng = rfl(E.ctl[g].rng);
+    make_move(s, mv, E.rules);
+    if (s.err == 0) {  // a throwing move leaves the stored game untouched
+        ws_store(s, E.state + (size_t)g * GREC);
+        if (lane_id() == 0) E.ctl[g].rng = s.rng;
+    }
+    if (lane_id() == 0) rc[g] = (uint8_t)s.err;
+}
+
+__global__ __launch_bounds__(64) void k_status(Dev E, int8_t* out)
+{
+    const int g = blockIdx.x;
+    WS s;
+    ws_load(s, E.state + (size_t)g * GREC);
+    int st = game_status(s, E.rules);
+    if (lane_id() == 0) out[g] = (int8_t)st;
+}
+
+__global__ __launch_bounds__(64) void k_encode(Dev E, uint8_t* out /*[G][88]*/)
+{
+    const int g = blockIdx.x;
+    WS s;
+    ws_load(s, E.state + (size_t)g * GREC);
+    encode88(s, out + (size_t)g * 88);
+}
+
+// reference `Data` image (160 B) -> 64-B record.  The five masks / totalArmy of the image are derived data and
+// are ignored on import (recomputed on export).
+__global__ __launch_bounds__(64) void k_import160(Dev E, const uint8_t* data160)
+{
+    const int g = blockIdx.x;
+    const uint8_t* d = data160 + (size_t)g * 160;
+    const uint32_t l = lane_id();
+    uint32_t b = 0;
+    if (l < LANDS) b = d[l];
+    b = l == GR_CUR ? d[146] : b;
+    b = l == GR_CARD_SETS ? d[147] : b;
+    b = l == GR_REINF ? d[148] : b;
+    b = l == GR_PHASE ? d[149] : b;
+    b = l == GR_MOB_FROM ? d[150] : b;
+    b = l == GR_MOB_TO ? d[151] : b;
+    b = l == GR_ALLOW_DRAW ? d[152] : b;
+    b = l == GR_ATTACKS ? d[153] : b;
+    b = l == GR_ROUND_LO ? d[144] : b;
+    b = l == GR_ROUND_HI ? d[145] : b;
+    b = l == GR_CARDS0 ? d[48 + 40] : b;
+    b = l == GR_CARDS1 ? d[96 + 40] : b;
+    E.state[(size_t)g * GREC + l] = (uint8_t)b;
+}
+
+__global__ __launch_bounds__(64) void k_export160(Dev E, uint8_t* data160)
+{
+    const int g = blockIdx.x;
+    uint8_t* d = data160 + (size_t)g * 160;
+    const uint32_t l = lane_id();
+    WS s;
+    ws_load(s, E.state + (size_t)g * GREC);
+    for (uint32_t i = l; i < 160; i += 64) d[i] = 0;
+    wave_mem_sync();
+    if (l < LANDS) d[l] = (uint8_t)s.la;
+    for (uint32_t p = 0; p < 2; p++) {
+        uint64_t m[5] = {m_owned(s, p), m_owned_army(s, p), m_owned_full(s, p), m_attack(s, p), m_attack_army(s, p)};
+        int ta = total_army(s, p);
+        uint8_t* q = d + 48 + 48 * p;
+        if (l < 30) {  // 5 masks x 6 bytes
+            uint32_t k = l / 6, by = l % 6;
+            q[8 * k + by] = (uint8_t)(m[k] >> (8 * by));
+        }
+        if (l == 30) q[38] = (uint8_t)(ta & 0xff);
+        if (l == 31) q[39] = (uint8_t)((ta >> 8) & 0xff);
+        if (l == 32) q[40] = (uint8_t)cards_of(s, p);
+    }
+    if (l == 0) {
+        d[144] = (uint8_t)(s.round & 0xff); d[145] = (uint8_t)(s.round >> 8); d[146] = (uint8_t)s.cur;
+        d[147] = (uint8_t)s.card_sets; d[148] = (uint8_t)s.reinf; d[149] = (uint8_t)s.phase;
+        d[150] = (uint8_t)s.mob_from; d[151] = (uint8_t)s.mob_to; d[152] = (uint8_t)s.allow_draw;
+        d[153] = (uint8_t)s.attacks;
+    }
+}
+
+// ================================================================================================
+// search kernels
+// ================================================================================================
+__global__ __launch_bounds__(64) void k_tree_clear(Dev E)
+{
+    const int g = blockIdx.x;
+    Ctl c;
+    ctl_load(c, &E.ctl[g]);
+    Tree t = tree_of(E, g);
+    // hiwater may be stale at creation: clear everything the pool can hold
+    c.hiwater = (uint32_t)E.C;
+    tree_clear(t, c);
+    c.pending = 0; c.path_len = 0; c.sims_done = 0; c.search_done = 1;
+    ctl_store(c, &E.ctl[g]);
+}
+
+__global__ __launch_bounds__(64) void k_tree_trim(Dev E)
+{
+    const int g = blockIdx.x;
+    Ctl c;
+    ctl_load(c, &E.ctl[g]);
+    Tree t = tree_of(E, g);
+    tree_trim(t, c);
+    ctl_store(c, &E.ctl[g]);
+}
+
+// AlphaZeroMCTS::simulate prologue (setRootState's trimNodes) for host-stepped searches
+__global__ __launch_bounds__(64) void k_search_begin(Dev E)
+{
+    const int g = blockIdx.x;
+    Ctl c;
+    ctl_load(c, &E.ctl[g]);
+    Tree t = tree_of(E, g);
+    WS s;
+    ws_load(s, E.state + (size_t)g * GREC);
+    tree_trim(t, c);
+    c.mode = 1;
+    c.sims_done = 0; c.pending = 0; c.path_len = 0; c.error = 0;
+    c.search_done = game_status(s, E.rules) != ST_NOT_ENDED ? 1u : 0u;
+    ctl_store(c, &E.ctl[g]);
+}
+
+// packs one finished game's staged records into the 265-byte on-disk layout (alphazero_nn_data.cpp:123-130)
+__device__ __forceinline__ void flush_samples(const Dev& E, int g, uint32_t n, int status, unsigned long long& dropped)
+{
+    if (n == 0) return;
+    unsigned long long start = 0;
+    if (lane_id() == 0) start = atomicAdd(E.ring_count, (unsigned long long)n);
+    start = rfl64(start);
+    const uint8_t* st = E.stage + (size_t)g * E.SCAP * STAGE_BYTES;
+    for (uint32_t r = 0; r < n; r++) {
+        unsigned long long slot = start + r;
+        if (slot >= E.ring_cap) { dropped += 1; continue; }
+        const uint8_t* src = st + (size_t)r * STAGE_BYTES;
+        uint8_t* dst = E.ring + (size_t)slot * AZR_RECORD_BYTES;
+        uint32_t player = rfl((uint32_t)src[260]);
+        // NNTrainDataStorage::updateValues (alphazero_nn_data.cpp:51-65)
+        float z = status == ST_DRAW ? 0.0f : ((int)player == status ? 1.0f : -1.0f);
+        uint32_t zb = __float_as_uint(z);
+        for (uint32_t j = lane_id(); j < AZR_RECORD_BYTES; j += 64) {
+            uint8_t b;
+            if (j == 0) b = (uint8_t)player;
+            else if (j < 89) b = src[j - 1];
+            else if (j < 93) b = (uint8_t)(zb >> (8 * (j - 89)));
+            else b = src[88 + (j - 93)];
+            dst[j] = b;
+        }
+    }
+}
+
+// One tree step for game g: consume the pending leaf's (pi, v) [expand + backup], then run searches — and in
+// self-play mode decisions, moves and game restarts — until the next leaf that needs the net.
+template <bool SELFPLAY>
+__global__ __launch_bounds__(64) void k_tree_step(Dev E)
+{
+    __shared__ int8_t scratch[128];
+    const int g = blockIdx.x;
+    Ctl c;
+    ctl_load(c, &E.ctl[g]);
+    if (c.mode == 0 || (!SELFPLAY && c.search_done)) return;
+    Tree t = tree_of(E, g);
+    const Rules R = E.rules;
+    const Search S = E.search;
+    WS root;
+    ws_load(root, E.state + (size_t)g * GREC);
+    unsigned long long n_sims = 0, n_evals = 0, n_levels = 0, n_dec = 0, n_games = 0, n_samples = 0, n_drop = 0,
+                       n_err = 0, n_ringdrop = 0;
+    bool root_dirty = false;
+
+    if (c.pending) {  // AlphaZeroMCTS::search leaf branch, after the future resolved (alphazero_mcts.cpp:350-356)
+        const uint32_t l = lane_id();
+        float pi = E.net_pi[(size_t)g * PI_STRIDE + (l < MOVES ? l : 0)];
+        float v = rdlf(E.net_v[g], 0);
+        uint64_t valid = rfl64(E.leaf_valid[g]);
+        uint32_t kd = reinterpret_cast<const uint32_t*>(E.leaf_key + (size_t)g * GREC)[l & 15u];
+        uint32_t h = rfl(E.leaf_hash[g]);
+        float prior = normalize_prior(pi, valid);
+        if (tree_expand(t, c, kd, h, valid, prior) == NO_NODE) n_drop++;
+        n_evals++;
+        if (c.path_len > 0) {  // path_len == 0: this was setRootState's root expansion (not a simulation)
+            tree_backup(t, c.path_len, v);
+            c.sims_done++;
+            n_sims++;
+        }
+        c.pending = 0;
+    }
+
+    for (;;) {
+        if ((int)c.sims_done >= S.simulations) {
+            if (!SELFPLAY) { c.search_done = 1; break; }
+            // ---- one decision of the trainer's move loop (alphazero_trainer.cpp:91-112) ----
+            root.rng = c.rng;
+            uint32_t rkd = ws_record_dword(root);
+            uint32_t ridx = tree_lookup(t, rkd, key_hash(rkd));
+            uint32_t mv = NONE;
+            if (ridx != NO_NODE) {
+                const uint8_t* n = node_ptr(t, ridx);
+                const uint32_t l = lane_id();
+                uint32_t N = reinterpret_cast<const uint32_t*>(n + ND_N)[l < MOVES ? l : 0];
+                uint64_t valid = (uint64_t)rfl(*reinterpret_cast<const uint32_t*>(n + ND_VALID_LO)) |
+                                 ((uint64_t)rfl(*reinterpret_cast<const uint32_t*>(n + ND_VALID_HI)) << 32);
+                float pi = root_policy(N, valid);
+                mv = (int)root.round > S.temperature_threshold ? pick_highest(pi) : pick_random(root, pi);
+                if (c.nsamples < (uint32_t)E.SCAP) {
+                    uint8_t* rec = E.stage + ((size_t)g * E.SCAP + c.nsamples) * STAGE_BYTES;
+                    encode88(root, rec);
+                    if (l < MOVES) reinterpret_cast<float*>(rec + 88)[l] = pi;
+                    if (l == 0) rec[260] = (uint8_t)root.cur;
+                    c.nsamples++;
+                } else n_ringdrop++;
+            }
+            if (mv != NONE) make_move(root, mv, R); else root.err = E_LOGIC;
+            c.last_move = mv;
+            c.decisions++;
+            n_dec++;
+            int st = root.err ? ST_NOT_ENDED : game_status(root, R);
+            if (root.err || st != ST_NOT_ENDED) {
+                if (root.err) { n_err++; c.error = root.err; }
+                else {
+                    wave_mem_sync();
+                    flush_samples(E, g, c.nsamples, st, n_ringdrop);
+                    n_samples += c.nsamples;
+                    n_games++;
+                }
+                c.status = st;
+                // next game in this slot: seeds base + g, base + G + g, ...
+                c.game_no++;
+                c.seed = E.base_seed + c.game_no * (uint32_t)E.G + (uint32_t)g;
+                ws_blank(root);
+                root.rng = rng_seed(c.seed);
+                new_game(root);
+                c.nsamples = 0; c.decisions = 0;
+                tree_clear(t, c);
+            }
+            c.rng = root.rng;
+            root_dirty = true;
+            tree_trim(t, c);
+            c.sims_done = 0;
+        }
+        // ---- AlphaZeroMCTS::search from the root (alphazero_mcts.cpp:322-377), iteratively ----
+        WS s = root;
+        s.rng = c.rng;
+        s.err = 0;
+        uint32_t plen = 0;
+        bool leaf = false, fail = false;
+        for (;;) {
+            int gs = game_status(s, R);
+            if (gs != ST_NOT_ENDED) {
+                float v = gs == ST_DRAW ? 0.0f : (gs == (int)s.cur ? 1.0f : -1.0f);
+                tree_backup(t, plen, v);
+                c.sims_done++;
+                n_sims++;
+                break;
+            }
+            uint64_t valid = valid_moves(s, R);
+            if (valid == 0) { fail = true; s.err = E_INVALID_ARGUMENT; break; }
+            uint32_t kd = ws_record_dword(s);
+            uint32_t h = key_hash(kd);
+            uint32_t idx = tree_lookup(t, kd, h);
+            if (idx == NO_NODE) {  // leaf: hand the position to the NN service
+                encode88(s, E.leaf_in + (size_t)g * LEAF_STRIDE);
+                const uint32_t l = lane_id();
+                if (l < 16) reinterpret_cast<uint32_t*>(E.leaf_key + (size_t)g * GREC)[l] = kd;
+                if (l == 0) { E.leaf_valid[g] = valid; E.leaf_hash[g] = h; }
+                leaf = true;
+                break;
+            }
+            n_levels++;
+            uint32_t mv = tree_select(t, idx, S, c.search_id, scratch);
+            if (mv == NONE) { fail = true; s.err = E_LOGIC; break; }
+            uint32_t before = s.cur;
+            make_move(s, mv, R);
+            if (s.err) { fail = true; break; }
+            if ((int)plen >= t.DMAX) { fail = true; s.err = AZR_E_CAPACITY; break; }
+            if (lane_id() == 0) t.path[plen] = idx | (mv << 16) | ((s.cur != before ? 1u : 0u) << 24);
+            plen++;
+        }
+        c.rng = s.rng;
+        if (fail) {
+            n_err++;
+            c.error = s.err;
+            if (SELFPLAY) {  // abandon the game (the reference would have thrown): restart the slot
+                c.game_no++;
+                c.seed = E.base_seed + c.game_no * (uint32_t)E.G + (uint32_t)g;
+                ws_blank(root);
+                root.rng = rng_seed(c.seed);
+                new_game(root);
+                c.rng = root.rng;
+                c.nsamples = 0; c.decisions = 0; c.sims_done = 0;
+                tree_clear(t, c);
+                tree_trim(t, c);
+                root_dirty = true;
+                continue;
+            }
+            c.search_done = 1;
+            break;
+        }
+        if (leaf) {
+            c.pending = 1;
+            c.path_len = plen;
+            break;
+        }
+    }
+    if (root_dirty) ws_store(root, E.state + (size_t)g * GREC);
+    ctl_store(c, &E.ctl[g]);
+    if (lane_id() == 0) {
+        if (c.pending) atomicAdd(E.active, 1u);
+        Counters* k = E.counters;
+        if (n_sims) atomicAdd(&k->simulations, n_sims);
+        if (n_evals) atomicAdd(&k->evaluations, n_evals);
+        if (n_levels) atomicAdd(&k->levels, n_levels);
+        if (n_dec) atomicAdd(&k->decisions, n_dec);
+        if (n_games) atomicAdd(&k->games_finished, n_games);
+        if (n_samples) atomicAdd(&k->samples, n_samples);
+        if (n_drop) atomicAdd(&k->nodes_dropped, n_drop);
+        if (n_err) atomicAdd(&k->errors, n_err);
+        if (n_ringdrop) atomicAdd(&k->ring_dropped, n_ringdrop);
+    }
+}
+
+// root statistics / policy / pick for host-stepped use
+__global__ __launch_bounds__(64) void k_root_stats(Dev E, uint32_t* n_out, float* q_out, float* p_out, float* pi_out)
+{
+    const int g = blockIdx.x;
+    Ctl c;
+    ctl_load(c, &E.ctl[g]);
+    Tree t = tree_of(E, g);
+    WS root;
+    ws_load(root, E.state + (size_t)g * GREC);
+    uint32_t kd = ws_record_dword(root);
+    uint32_t idx = tree_lookup(t, kd, key_hash(kd));
+    const uint32_t l = lane_id();
+    uint32_t N = 0; float Q = 0, P = 0, pi = 0;
+    if (idx != NO_NODE) {
+        const uint8_t* n = node_ptr(t, idx);
+        N = reinterpret_cast<const uint32_t*>(n + ND_N)[l < MOVES ? l : 0];
+        Q = reinterpret_cast<const float*>(n + ND_Q)[l < MOVES ? l : 0];
+        P = reinterpret_cast<const float*>(n + ND_P)[l < MOVES ? l : 0];
+        uint64_t valid = (uint64_t)rfl(*reinterpret_cast<const uint32_t*>(n + ND_VALID_LO)) |
+                         ((uint64_t)rfl(*reinterpret_cast<const uint32_t*>(n + ND_VALID_HI)) << 32);
+        pi = root_policy(N, valid);
+    }
+    if (l < MOVES) {
+        if (n_out) n_out[(size_t)g * MOVES + l] = N;
+        if (q_out) q_out[(size_t)g * MOVES + l] = Q;
+        if (p_out) p_out[(size_t)g * MOVES + l] = P;
+        if (pi_out) pi_out[(size_t)g * MOVES + l] = pi;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_pick(Dev E, int sample, uint8_t* moves)
+{
+    const int g = blockIdx.x;
+    Ctl c;
+    ctl_load(c, &E.ctl[g]);
+    Tree t = tree_of(E, g);
+    WS root;
+    ws_load(root, E.state + (size_t)g * GREC);
+    root.rng = c.rng;
+    uint32_t kd = ws_record_dword(root);
+    uint32_t idx = tree_lookup(t, kd, key_hash(kd));
+    uint32_t mv = NONE;
+    if (idx != NO_NODE) {
+        const uint8_t* n = node_ptr(t, idx);
+        const uint32_t l = lane_id();
+        uint32_t N = reinterpret_cast<const uint32_t*>(n + ND_N)[l < MOVES ? l : 0];
+        uint64_t valid = (uint64_t)rfl(*reinterpret_cast<const uint32_t*>(n + ND_VALID_LO)) |
+                         ((uint64_t)rfl(*reinterpret_cast<const uint32_t*>(n + ND_VALID_HI)) << 32);
+        float pi = root_policy(N, valid);
+        mv = sample ? pick_random(root, pi) : pick_highest(pi);
+    }
+    if (lane_id() == 0) {
+        moves[g] = (uint8_t)mv;
+        E.ctl[g].rng = root.rng;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_selfplay_start(Dev E)
+{
+    const int g = blockIdx.x;
+    Ctl c;
+    ctl_load(c, &E.ctl[g]);
+    Tree t = tree_of(E, g);
+    c.hiwater = (uint32_t)E.C;
+    tree_clear(t, c);
+    tree_trim(t, c);
+    c.mode = 2; c.sims_done = 0; c.pending = 0; c.path_len = 0; c.search_done = 0; c.error = 0;
+    c.game_no = 0; c.nsamples = 0; c.decisions = 0; c.status = ST_NOT_ENDED;
+    c.seed = E.base_seed + (uint32_t)g;
+    WS s;
+    ws_blank(s);
+    s.rng = rng_seed(c.seed);
+    new_game(s);
+    c.rng = s.rng;
+    ws_store(s, E.state + (size_t)g * GREC);
+    ctl_store(c, &E.ctl[g]);
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+static int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+extern "C" void azr_default_settings(azr_settings* s)
+{
+    memset(s, 0, sizeof *s);
+    s->device = 0;
+    s->games = 32;
+    s->blocks = 20;
+    s->net_dtype = AZR_NET_BF16;
+    s->mcts_simulations = 32;
+    s->allow_yield = 1;
+    s->limit_reinforcement = 1;
+    s->limit_attack = 0;
+    s->max_game_rounds = 30 + 28;
+    s->min_unit_move = 3;
+    s->temperature_threshold = 15 + 28;
+    s->hp_exploration = 1.1f;
+    s->dir_noise_value = 0.3f;
+    s->dir_noise_epsi = 0.25f;
+    s->node_capacity = 0;
+    s->sample_capacity = 0;
+}
+
+template <typename T>
+static hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, n * sizeof(T)); }
+
+extern "C" int azr_engine_create(const azr_settings* s, azr_engine** out)
+{
+    if (!s || !out || s->games <= 0 || s->blocks <= 0 || s->mcts_simulations < 0) return AZR_E_INVALID_ARGUMENT;
+    azr_engine* h = new (std::nothrow) azr_engine();
+    if (!h) return AZR_E_HIP;
+    h->cfg = *s;
+    h->mode = 0;
+    h->weights_set = false;
+    h->prof_net_ms = h->prof_tree_ms = 0;
+    h->prof_launches = 0;
+    *out = h;
+    HIPCHK(h, hipSetDevice(s->device));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    Dev& d = h->d;
+    memset(&d, 0, sizeof d);
+    d.G = s->games;
+    int C = s->node_capacity > 0 ? s->node_capacity : 16 * (s->mcts_simulations + 1);
+    if (C < 64) C = 64;
+    if (C > 65534) C = 65534;
+    d.C = C;
+    d.H = next_pow2(2 * C);
+    d.DMAX = std::min(C, 1024);
+    d.SCAP = s->sample_capacity > 0 ? s->sample_capacity : 4096;
+    d.rules = Rules{s->allow_yield, s->limit_reinforcement, s->limit_attack, s->max_game_rounds, s->min_unit_move};
+    d.search.simulations = s->mcts_simulations;
+    d.search.c1 = 1 - s->dir_noise_epsi;
+    d.search.c2 = s->dir_noise_epsi * s->dir_noise_value;
+    d.search.hp = s->hp_exploration;
+    d.search.temperature_threshold = s->temperature_threshold;
+    const size_t G = d.G;
+    HIPCHK(h, dmalloc(&d.state, G * GREC));
+    HIPCHK(h, dmalloc(&d.ctl, G));
+    HIPCHK(h, dmalloc(&d.nodes, G * C * NODE_BYTES));
+    HIPCHK(h, dmalloc(&d.touch, G * C));
+    HIPCHK(h, dmalloc(&d.nhash, G * C));
+    HIPCHK(h, dmalloc(&d.table, G * d.H));
+    HIPCHK(h, dmalloc(&d.freel, G * C));
+    HIPCHK(h, dmalloc(&d.path, G * d.DMAX));
+    HIPCHK(h, dmalloc(&d.leaf_in, G * LEAF_STRIDE));
+    HIPCHK(h, dmalloc(&d.leaf_key, G * GREC));
+    HIPCHK(h, dmalloc(&d.leaf_valid, G));
+    HIPCHK(h, dmalloc(&d.leaf_hash, G));
+    HIPCHK(h, dmalloc(&d.net_pi, G * PI_STRIDE));
+    HIPCHK(h, dmalloc(&d.net_v, G));
+    HIPCHK(h, dmalloc(&d.stage, G * d.SCAP * STAGE_BYTES));
+    d.ring_cap = (unsigned long long)G * d.SCAP;
+    HIPCHK(h, dmalloc(&d.ring, (size_t)d.ring_cap * AZR_RECORD_BYTES));
+    HIPCHK(h, dmalloc(&d.ring_count, 1));
+    HIPCHK(h, dmalloc(&d.counters, 1));
+    HIPCHK(h, dmalloc(&d.active, 1));
+    HIPCHK(h, hipMemsetAsync(d.state, 0, G * GREC, h->stream));
+    HIPCHK(h, hipMemsetAsync(d.ctl, 0, G * sizeof(Ctl), h->stream));
+    HIPCHK(h, hipMemsetAsync(d.touch, 0, G * C * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(d.table, 0, G * d.H * sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(d.leaf_in, 0, G * LEAF_STRIDE, h->stream));
+    HIPCHK(h, hipMemsetAsync(d.net_pi, 0, G * PI_STRIDE * sizeof(float), h->stream));
+    HIPCHK(h, hipMemsetAsync(d.net_v, 0, G * sizeof(float), h->stream));
+    HIPCHK(h, hipMemsetAsync(d.ring_count, 0, sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipMemsetAsync(d.counters, 0, sizeof(Counters), h->stream));
+    HIPCHK(h, hipMemsetAsync(d.active, 0, sizeof(uint32_t), h->stream));
+    int rc = net_alloc(h);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tree_clear, dim3(d.G), dim3(64), 0, h->stream, d);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return AZR_OK;
+}
+
+extern "C" int azr_engine_destroy(azr_engine* h)
+{
+    if (!h) return AZR_E_BAD_HANDLE;
+    hipSetDevice(h->cfg.device);
+    hipStreamSynchronize(h->stream);
+    Dev& d = h->d;
+    void* ptrs[] = {d.state, d.ctl, d.nodes, d.touch, d.nhash, d.table, d.freel, d.path, d.leaf_in, d.leaf_key,
+                    d.leaf_valid, d.leaf_hash, d.net_pi, d.net_v, d.stage, d.ring, d.ring_count, d.counters, d.active};
+    for (void* p : ptrs) if (p) hipFree(p);
+    net_free(h);
+    for (hipEvent_t e : h->ev) hipEventDestroy(e);
+    hipStreamDestroy(h->stream);
+    delete h;
+    return AZR_OK;
+}
+
+extern "C" const char* azr_last_error(const azr_engine* h) { return h ? h->err.c_str() : "bad handle"; }
+extern "C" int azr_engine_games(const azr_engine* h) { return h ? h->d.G : 0; }
+
+// staging helpers: synchronous copies through temporary device buffers (boundary calls are not the hot path)
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+};
+#define H2D(h, dst, src, n) HIPCHK(h, hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, (h)->stream))
+#define D2H(h, dst, src, n) HIPCHK(h, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, (h)->stream))
+#define SYNC(h) HIPCHK(h, hipStreamSynchronize((h)->stream))
+#define LAUNCH(h, kern, ...)                                                          \
+    do {                                                                              \
+        hipLaunchKernelGGL(kern, dim3((h)->d.G), dim3(64), 0, (h)->stream, __VA_ARGS__); \
+        HIPCHK(h, hipGetLastError());                                                 \
+    } while (0)
+#define ENTER(h)                                 \
+    if (!(h)) return AZR_E_BAD_HANDLE;           \
+    HIPCHK(h, hipSetDevice((h)->cfg.device))
+
+extern "C" int azr_engine_new_games(azr_engine* h, const uint32_t* seeds)
+{
+    ENTER(h);
+    if (!seeds) return AZR_E_INVALID_ARGUMENT;
+    DevBuf b;
+    HIPCHK(h, b.alloc(h->d.G * 4));
+    H2D(h, b.p, seeds, (size_t)h->d.G * 4);
+    LAUNCH(h, k_new_games, h->d, (const uint32_t*)b.p);
+    LAUNCH(h, k_tree_clear, h->d);
+    SYNC(h);
+    return AZR_OK;
+}
+
+extern "C" int azr_engine_set_states(azr_engine* h, const void* data160)
+{
+    ENTER(h);
+    if (!data160) return AZR_E_INVALID_ARGUMENT;
+    DevBuf b;
+    HIPCHK(h, b.alloc((size_t)h->d.G * 160));
+    H2D(h, b.p, data160, (size_t)h->d.G * 160);
+    LAUNCH(h, k_import160, h->d, (const uint8_t*)b.p);
+    SYNC(h);
+    return AZR_OK;
+}
+
+extern "C" int azr_engine_get_states(azr_engine* h, void* data160)
+{
+    ENTER(h);
+    if (!data160) return AZR_E_INVALID_ARGUMENT;
+    DevBuf b;
+    HIPCHK(h, b.alloc((size_t)h->d.G * 160));
+    LAUNCH(h, k_export160, h->d, (uint8_t*)b.p);
+    D2H(h, data160, b.p, (size_t)h->d.G * 160);
+    SYNC(h);
+    return AZR_OK;
+}
+
+extern "C" int azr_engine_set_rng(azr_engine* h, const uint32_t* st)
+{
+    ENTER(h);
+    if (!st) return AZR_E_INVALID_ARGUMENT;
+    HIPCHK(h, hipMemcpy2DAsync(&h->d.ctl[0].rng, sizeof(Ctl), st, 4, 4, h->d.G, hipMemcpyHostToDevice, h->stream));
+    SYNC(h);
+    return AZR_OK;
+}
+
+extern "C" int azr_engine_get_rng(azr_engine* h, uint32_t* st)
+{
+    ENTER(h);
+    if (!st) return AZR_E_INVALID_ARGUMENT;
+    HIPCHK(h, hipMemcpy2DAsync(st, 4, &h->d.ctl[0].rng, sizeof(Ctl), 4, h->d.G, hipMemcpyDeviceToHost, h->stream));
+    SYNC(h);
+    return AZR_OK;
+}
+
+extern "C" int azr_engine_valid_moves(azr_engine* h, uint64_t* masks)
+{
+    ENTER(h);
+    if (!masks) return AZR_E_INVALID_ARGUMENT;
+    DevBuf b;
+    HIPCHK(h, b.alloc((size_t)h->d.G * 8));
+    LAUNCH(h, k_valid_moves, h->d, (uint64_t*)b.p);
+    D2H(h, masks, b.p, (size_t)h->d.G * 8);
+    SYNC(h);
+    return AZR_OK;
+}
+
+extern "C" int azr_engine_make_moves(azr_engine* h, const uint8_t* moves, uint8_t* rc)
+{
+    ENTER(h);
+    if (!moves) return AZR_E_INVALID_ARGUMENT;
+    DevBuf b, r;
+    HIPCHK(h, b.alloc(h->d.G));
+    HIPCHK(h, r.alloc(h->d.G));
+    H2D(h, b.p, moves, (size_t)h->d.G);
+    LAUNCH(h, k_make_moves, h->d, (const uint8_t*)b.p, (uint8_t*)r.p);
+    std::vector<uint8_t> tmp(h->d.G);
+    D2H(h, tmp.data(), r.p, (size_t)h->d.G);
+    SYNC(h);
+    int worst = AZR_OK;
+    for (int g = 0; g < h->d.G; g++) {
+        if (rc) rc[g] = tmp[g];
+        if (tmp[g] && !worst) worst = tmp[g];
+    }
+    return rc ? AZR_OK : worst;
+}
+
+extern "C" int azr_engine_status(azr_engine* h, int8_t* status)
+{
+    ENTER(h);
+    if (!status) return AZR_E_INVALID_ARGUMENT;
+    DevBuf b;
+    HIPCHK(h, b.alloc(h->d.G));
+    LAUNCH(h, k_status, h->d, (int8_t*)b.p);
+    D2H(h, status, b.p, (size_t)h->d.G);
+    SYNC(h);
+    return AZR_OK;
+}
+
+extern "C" int azr_engine_encode(azr_engine* h, void* in88)
+{
+    ENTER(h);
+    if (!in88) return AZR_E_INVALID_ARGUMENT;
+    DevBuf b;
+    HIPCHK(h, b.alloc((size_t)h->d.G * 88));
+    HIPCHK(h, hipMemsetAsync(b.p, 0, (size_t)h->d.G * 88, h->stream));
+    LAUNCH(h, k_encode, h->d, (uint8_t*)b.p);
+    D2H(h, in88, b.p, (size_t)h->d.G * 88);
+    SYNC(h);
+    return AZR_OK;
+}
+
+// ---- search ---------------------------------------------------------------------------------------
+extern "C" int azr_mcts_clear(azr_engine* h)
+{
+    ENTER(h);
+    LAUNCH(h, k_tree_clear, h->d);
+    SYNC(h);
+    return AZR_OK;
+}
+
+extern "C" int azr_mcts_trim(azr_engine* h)
+{
+    ENTER(h);
+    LAUNCH(h, k_tree_trim, h->d);
+    SYNC(h);
+    return AZR_OK;
+}
+
+extern "C" int azr_mcts_begin(azr_engine* h)
+{
+    ENTER(h);
+    h->mode = 1;
+    LAUNCH(h, k_search_begin, h->d);
+    SYNC(h);
+    return AZR_OK;
+}
+
+static int tree_step_host(azr_engine* h, uint32_t* active)
+{
+    HIPCHK(h, hipMemsetAsync(h->d.active, 0, 4, h->stream));
+    LAUNCH(h, k_tree_step<false>, h->d);
+    D2H(h, active, h->d.active, 4);
+    SYNC(h);
+    return AZR_OK;
+}
+
+extern "C" int azr_mcts_leaves(azr_engine* h, void* in88, uint8_t* need, int* active_out)
+{
+    ENTER(h);
+    uint32_t active = 0;
+    int rc = tree_step_host(h, &active);
+    if (rc) return rc;
+    const int G = h->d.G;
+    if (in88) HIPCHK(h, hipMemcpy2DAsync(in88, 88, h->d.leaf_in, LEAF_STRIDE, 88, G, hipMemcpyDeviceToHost, h->stream));
+    if (need) {
+        std::vector<uint32_t> p(G);
+        HIPCHK(h, hipMemcpy2DAsync(p.data(), 4, &h->d.ctl[0].pending, sizeof(Ctl), 4, G, hipMemcpyDeviceToHost, h->stream));
+        SYNC(h);
+        for (int g = 0; g < G; g++) need[g] = (uint8_t)p[g];
+    }
+    SYNC(h);
+    if (active_out) *active_out = (int)active;
+    return AZR_OK;
+}
+
+extern "C" int azr_mcts_apply(azr_engine* h, const float* pi, const float* v)
+{
+    ENTER(h);
+    if (!pi || !v) return AZR_E_INVALID_ARGUMENT;
+    const int G = h->d.G;
+    HIPCHK(h, hipMemcpy2DAsync(h->d.net_pi, PI_STRIDE * 4, pi, MOVES * 4, MOVES * 4, G, hipMemcpyHostToDevice, h->stream));
+    H2D(h, h->d.net_v, v, (size_t)G * 4);
+    SYNC(h);
+    return AZR_OK;
+}
+
+extern "C" int azr_mcts_simulate(azr_engine* h)
+{
+    ENTER(h);
+    if (!h->weights_set) { h->err = "azr_mcts_simulate: no weights (azr_nn_init_random / azr_nn_set_weights / azr_nn_load)"; return AZR_E_STATE; }
+    int rc = azr_mcts_begin(h);
+    if (rc) return rc;
+    for (;;) {
+        uint32_t active = 0;
+        rc = tree_step_host(h, &active);
+        if (rc) return rc;
+        if (active == 0) break;
+        rc = net_forward(h, h->d.leaf_in, LEAF_STRIDE, h->d.G, h->d.net_pi, h->d.net_v);
+        if (rc) return rc;
+    }
+    // surface per-game errors
+    std::vector<uint32_t> e(h->d.G);
+    HIPCHK(h, hipMemcpy2DAsync(e.data(), 4, &h->d.ctl[0].error, sizeof(Ctl), 4, h->d.G, hipMemcpyDeviceToHost, h->stream));
+    SYNC(h);
+    for (int g = 0; g < h->d.G; g++)
+        if (e[g]) { h->err = "search error in game " + std::to_string(g) + " code " + std::to_string(e[g]); return (int)e[g]; }
+    return AZR_OK;
+}
+
+extern "C" int azr_mcts_root_stats(azr_engine* h, uint32_t* n, float* q, float* p)
+{
+    ENTER(h);
+    const size_t sz = (size_t)h->d.G * MOVES * 4;
+    DevBuf bn, bq, bp;
+    HIPCHK(h, bn.alloc(sz)); HIPCHK(h, bq.alloc(sz)); HIPCHK(h, bp.alloc(sz));
+    LAUNCH(h, k_root_stats, h->d, (uint32_t*)bn.p, (float*)bq.p, (float*)bp.p, (float*)nullptr);
+    if (n) D2H(h, n, bn.p, sz);
+    if (q) D2H(h, q, bq.p, sz);
+    if (p) D2H(h, p, bp.p, sz);
+    SYNC(h);
+    return AZR_OK;
+}
+
+extern "C" int azr_mcts_policy(azr_engine* h, float* pi)
+{
+    ENTER(h);
+    if (!pi) return AZR_E_INVALID_ARGUMENT;
+    const size_t sz = (size_t)h->d.G * MOVES * 4;
+    DevBuf b;
+    HIPCHK(h, b.alloc(sz));
+    LAUNCH(h, k_root_stats, h->d, (uint32_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)b.p);
+    D2H(h, pi, b.p, sz);
+    SYNC(h);
+    return AZR_OK;
+}
+
+extern "C" int azr_mcts_pick(azr_engine* h, int sample, uint8_t* moves)
+{
+    ENTER(h);
+    if (!moves) return AZR_E_INVALID_ARGUMENT;
+    DevBuf b;
+    HIPCHK(h, b.alloc(h->d.G));
+    LAUNCH(h, k_pick, h->d, sample, (uint8_t*)b.p);
+    D2H(h, moves, b.p, (size_t)h->d.G);
+    SYNC(h);
+    return AZR_OK;
+}
+
+// ---- device-resident self-play ------------------------------------------------------------------------
+extern "C" int azr_selfplay_start(azr_engine* h, uint32_t base_seed)
+{
+    ENTER(h);
+    h->d.base_seed = base_seed;
+    h->mode = 2;
+    HIPCHK(h, hipMemsetAsync(h->d.counters, 0, sizeof(Counters), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d.ring_count, 0, sizeof(unsigned long long), h->stream));
+    LAUNCH(h, k_selfplay_start, h->d);
+    SYNC(h);
+    return AZR_OK;
+}
+
+extern "C" int azr_selfplay_run(azr_engine* h, int passes)
+{
+    ENTER(h);
+    if (h->mode != 2) { h->err = "azr_selfplay_run: call azr_selfplay_start first"; return AZR_E_STATE; }
+    if (!h->weights_set) { h->err = "azr_selfplay_run: no weights"; return AZR_E_STATE; }
+    const int PROF_MAX = 512;  // launches timed with events (spread over the run)
+    const int nprof = std::min(passes, PROF_MAX);
+    while ((int)h->ev.size() < 3 * PROF_MAX) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreate(&e));
+        h->ev.push_back(e);
+    }
+    const int stride = passes > nprof ? passes / nprof : 1;
+    int k = 0;
+    for (int p = 0; p < passes; p++) {
+        const bool prof = (p % stride == 0) && k < nprof;
+        if (prof) HIPCHK(h, hipEventRecord(h->ev[3 * k + 0], h->stream));
+        LAUNCH(h, k_tree_step<true>, h->d);
+        if (prof) HIPCHK(h, hipEventRecord(h->ev[3 * k + 1], h->stream));
+        int rc = net_forward(h, h->d.leaf_in, LEAF_STRIDE, h->d.G, h->d.net_pi, h->d.net_v);
+        if (rc) return rc;
+        if (prof) { HIPCHK(h, hipEventRecord(h->ev[3 * k + 2], h->stream)); k++; }
+    }
+    SYNC(h);
+    double tn = 0, tt = 0;
+    for (int i = 0; i < k; i++) {
+        float a = 0, b = 0;
+        HIPCHK(h, hipEventElapsedTime(&a, h->ev[3 * i + 0], h->ev[3 * i + 1]));
+        HIPCHK(h, hipEventElapsedTime(&b, h->ev[3 * i + 1], h->ev[3 * i + 2]));
+        tt += a; tn += b;
+    }
+    h->prof_launches = k;
+    h->prof_tree_ms = k ? (float)(tt / k) : 0;
+    h->prof_net_ms = k ? (float)(tn / k) : 0;
+    return AZR_OK;
+}
+
+extern "C" int azr_profile_last_run(azr_engine* h, float* net_ms, float* tree_ms, int* launches)
+{
+    if (!h) return AZR_E_BAD_HANDLE;
+    if (net_ms) *net_ms = h->prof_net_ms;
+    if (tree_ms) *tree_ms = h->prof_tree_ms;
+    if (launches) *launches = h->prof_launches;
+    return AZR_OK;
+}
+
+extern "C" int azr_selfplay_counters(azr_engine* h, azr_counters* out)
+{
+    ENTER(h);
+    if (!out) return AZR_E_INVALID_ARGUMENT;
+    Counters c;
+    D2H(h, &c, h->d.counters, sizeof c);
+    SYNC(h);
+    out->simulations = c.simulations; out->evaluations = c.evaluations; out->levels = c.levels;
+    out->decisions = c.decisions; out->games_finished = c.games_finished; out->samples = c.samples;
+    out->nodes_dropped = c.nodes_dropped; out->errors = c.errors;
+    return AZR_OK;
+}
+
+extern "C" int azr_samples_drain(azr_engine* h, void* rec265, size_t cap, size_t* n_out)
+{
+    ENTER(h);
+    unsigned long long n = 0;
+    D2H(h, &n, h->d.ring_count, 8);
+    SYNC(h);
+    if (n > h->d.ring_cap) n = h->d.ring_cap;
+    size_t take = std::min((size_t)n, cap);
+    if (take && rec265) D2H(h, rec265, h->d.ring, take * AZR_RECORD_BYTES);
+    HIPCHK(h, hipMemsetAsync(h->d.ring_count, 0, 8, h->stream));
+    SYNC(h);
+    if (n_out) *n_out = take;
+    return AZR_OK;
+}
+
+extern "C" int azr_samples_device_view(azr_engine* h, void** dev_ptr, size_t* n_out)
+{
+    ENTER(h);
+    unsigned long long n = 0;
+    D2H(h, &n, h->d.ring_count, 8);
+    SYNC(h);
+    if (n > h->d.ring_cap) n = h->d.ring_cap;
+    if (dev_ptr) *dev_ptr = h->d.ring;
+    if (n_out) *n_out = (size_t)n;
+    return AZR_OK;
+}
+
+extern "C" int azr_device_synchronize(azr_engine* h)
+{
+    ENTER(h);
+    SYNC(h);
+    return AZR_OK;
+}

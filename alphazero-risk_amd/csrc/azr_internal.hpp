@@ -1,0 +1,94 @@
+// azr_internal.hpp — engine object shared by the C-ABI translation units (host side).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/azr.h"
+#include "azr_tree.hpp"
+
+namespace azr {
+
+constexpr int LEAF_STRIDE = 96;    // in88 padded to 96 B per game
+constexpr int PI_STRIDE = 44;      // pi[43] padded
+constexpr int STAGE_BYTES = 264;   // staged record: in88 @0 | pi[43] @88 | player @260
+constexpr int NF = 256;            // FILTERS (python/src/build_graph.py:32)
+constexpr int NPOS = 42;
+
+// device view handed to kernels by value
+struct Dev {
+    int G, C, H, DMAX, SCAP;
+    Rules rules;
+    Search search;
+    uint8_t* state;        // [G][64] game records
+    Ctl* ctl;              // [G]
+    uint8_t* nodes;        // [G][C][NODE_BYTES]
+    uint32_t* touch;       // [G][C]
+    uint32_t* nhash;       // [G][C]
+    uint32_t* table;       // [G][H]
+    uint16_t* freel;       // [G][C]
+    uint32_t* path;        // [G][DMAX]
+    uint8_t* leaf_in;      // [G][LEAF_STRIDE]
+    uint8_t* leaf_key;     // [G][64]
+    uint64_t* leaf_valid;  // [G]
+    uint32_t* leaf_hash;   // [G]
+    float* net_pi;         // [G][PI_STRIDE]
+    float* net_v;          // [G]
+    uint8_t* stage;        // [G][SCAP][STAGE_BYTES]
+    uint8_t* ring;         // [RCAP][265]
+    unsigned long long* ring_count;
+    unsigned long long ring_cap;
+    Counters* counters;
+    uint32_t* active;      // number of games with a pending leaf after the last tree step
+    uint32_t base_seed;
+};
+
+// folded network parameters on device
+struct NetDev {
+    int blocks;
+    // fp32 path
+    float* stem_w;     // [9][13][256]
+    float* stem_scale; // [7] per board row (conv_bn, axis=1)
+    float* stem_shift; // [7]
+    float* tower_w;    // [2B][9][256][256]
+    float* tower_scale;// [2B][256]
+    float* tower_shift;// [2B][256]
+    float* d_flat;     // whole AZRW vector on device (fp32 conv kernels and the heads read it in place)
+    float* d_fold;     // folded BN: stem scale[7] shift[7]; per conv layer scale[256] shift[256]
+    const float* head; // head section of d_flat
+    // bf16 MFMA path
+    uint16_t* stem_wp;  // packed fragments
+    uint16_t* tower_wp; // packed fragments [2B][...]
+    // activations (fp32 path)
+    float* actX;       // [G][42][256]
+    float* actT;       // [G][42][256]
+};
+
+}  // namespace azr
+
+struct azr_engine {
+    azr_settings cfg;
+    azr::Dev d;
+    azr::NetDev net;
+    hipStream_t stream;
+    std::string err;
+    std::vector<float> flat;      // AZRW host copy
+    int mode;                     // 0 rules only / stepwise, 2 self-play
+    // profiling of the last azr_selfplay_run
+    std::vector<hipEvent_t> ev;
+    float prof_net_ms, prof_tree_ms;
+    int prof_launches;
+    bool weights_set;
+};
+
+namespace azr {
+// net (azr_net.hip)
+int net_alloc(azr_engine* h);
+void net_free(azr_engine* h);
+int net_upload(azr_engine* h);  // fold BN, pack, copy h->flat to the device
+int net_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v);
+size_t net_param_count(int blocks);
+void net_init_random(float* flat, int blocks, uint64_t seed);
+}  // namespace azr

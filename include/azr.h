@@ -1,0 +1,156 @@
+/* azr.h — C-ABI of the MI355X-native AlphaZero-Risk self-play hot path (libazr_hip.so).
+ *
+ * Drop-in boundary for the reference's three in-process seams (citations relative to the
+ * reference tree).  The reference has no FFI; these entry points are what a binding for each seam
+ * would call, batched over G concurrent games (one handle = one GPU = one HIP stream set; a handle is
+ * NOT re-entrant, different handles are independent — the reference's "one self-play thread per GPU",
+ * player/alpha_zero/alphazero_trainer.cpp:48-57).
+ *
+ * Conventions: every function returns 0 on success or an AZR_E_* code (no exceptions cross the ABI);
+ * the caller owns every buffer; `*_host` pointers are host memory, copied through pinned staging;
+ * byte images use the reference's own layouts:
+ *     state  = `struct Data`            160 B  (state/state.h:86-105)
+ *     in88   = `class NNInputData`       88 B  (neural_network/alphazero_nn_data.h:66-96)
+ *     rec265 = on-disk training record  265 B  (alphazero_nn_data.cpp:123-130: i8 player | in88 | f32 z | f32 pi[43])
+ * Policy index 0..41 = land, 42 = SKIP (land/land.cpp:312), 43 = None.
+ */
+#ifndef AZR_H
+#define AZR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZR_LANDS 42
+#define AZR_MOVES 43
+#define AZR_STATE_BYTES 160
+#define AZR_INPUT_BYTES 88
+#define AZR_RECORD_BYTES 265
+
+enum {
+    AZR_OK = 0,
+    AZR_E_INVALID_ARGUMENT = 1, /* std::invalid_argument in the reference (illegal phase/move) */
+    AZR_E_LOGIC = 2,            /* std::logic_error (army overflow, skip in a non-skippable phase) */
+    AZR_E_BAD_HANDLE = 3,
+    AZR_E_HIP = 4,              /* a HIP runtime call failed (TF_CHECK_OK abort in the reference) */
+    AZR_E_CAPACITY = 5,         /* node pool / path stack / sample buffer exhausted */
+    AZR_E_IO = 6,
+    AZR_E_STATE = 7             /* call not valid in the engine's current mode */
+};
+
+/* dtype of the policy/value net contractions */
+enum { AZR_NET_F32 = 0, AZR_NET_BF16 = 1 };
+
+/* Mirrors the fields of `class Settings` the hot path reads (src/settings.h:41-64) + engine sizing. */
+typedef struct azr_settings {
+    int32_t device;                /* HIP device ordinal */
+    int32_t games;                 /* G: concurrent games on this handle (gpu-games, settings.h:163-171) */
+    int32_t blocks;                /* residual blocks B (CMakeLists.txt:15 BLOCKS, 20) */
+    int32_t net_dtype;             /* AZR_NET_F32 | AZR_NET_BF16 */
+    int32_t mcts_simulations;      /* MCTS_SIMULATIONS (--mcts) */
+    int32_t allow_yield;           /* ALLOW_YIELD (--allow-yield) */
+    int32_t limit_reinforcement;   /* LIMIT_REINFORCEMENT_MOVES (--limit-reinforcement) */
+    int32_t limit_attack;          /* LIMIT_ATTACK_MOVES (--limit-attack) */
+    int32_t max_game_rounds;       /* MAX_GAME_ROUNDS 58 */
+    int32_t min_unit_move;         /* MIN_UNIT_MOVE 3 */
+    int32_t temperature_threshold; /* TEMPERATURE_TRESHOLD (--temp) */
+    float hp_exploration;          /* HP_EXPLORATION (--hp) */
+    float dir_noise_value;         /* DIR_NOISE_VALUE (--dnv) */
+    float dir_noise_epsi;          /* DIR_NOISE_EPSI (--dne) */
+    int32_t node_capacity;         /* tree nodes per game; 0 = 16 * (mcts_simulations + 1) */
+    int32_t sample_capacity;       /* (s,pi,z) records buffered per game before a drain; 0 = 4096 */
+} azr_settings;
+
+typedef struct azr_engine azr_engine;
+
+/* Settings() defaults (src/settings.h:22-81) */
+void azr_default_settings(azr_settings* s);
+
+int azr_engine_create(const azr_settings* s, azr_engine** out);
+int azr_engine_destroy(azr_engine* h);
+const char* azr_last_error(const azr_engine* h);
+int azr_engine_games(const azr_engine* h);
+
+/* ---- game rules: `class State` + UtilityNN (state/state.cpp, alphazero_moves.cpp) -------------------- */
+/* State::newGame (state.cpp:137-167) for game g with its own minstd_rand0 stream seeded seeds[g]
+ * (replaces the reference's process-global RNG, src/rng.h:50). */
+int azr_engine_new_games(azr_engine* h, const uint32_t* seeds_host);
+int azr_engine_set_states(azr_engine* h, const void* data160_host); /* [G][160] */
+int azr_engine_get_states(azr_engine* h, void* data160_host);       /* [G][160], padding bytes zero */
+int azr_engine_set_rng(azr_engine* h, const uint32_t* engine_state_host); /* raw minstd_rand0 state per game */
+int azr_engine_get_rng(azr_engine* h, uint32_t* engine_state_host);
+/* UtilityNN::getValidMoves (alphazero_moves.cpp:3-70): bit i = land i, bit 42 = SKIP */
+int azr_engine_valid_moves(azr_engine* h, uint64_t* masks_host);
+/* UtilityNN::makeMove (alphazero_moves.cpp:72-233); rc_host[g] (optional) = AZR_OK / AZR_E_INVALID_ARGUMENT /
+ * AZR_E_LOGIC per game, as the reference's throw sites; moves_host[g] = 255 leaves game g untouched. */
+int azr_engine_make_moves(azr_engine* h, const uint8_t* moves_host, uint8_t* rc_host);
+/* State::gameStatus (state.cpp:518-565): -1 running, 0/1 winner, -2 draw */
+int azr_engine_status(azr_engine* h, int8_t* status_host);
+/* NNInputData(const State&) (alphazero_nn_data.cpp:165-196) */
+int azr_engine_encode(azr_engine* h, void* in88_host); /* [G][88] */
+
+/* ---- NN service: AlphaZeroNNId (alphazero_gpu_cluster.h:14-47) ------------------------------------------ */
+size_t azr_nn_param_count(int blocks);                     /* floats in the AZRW flat vector */
+int azr_nn_init_random(azr_engine* h, uint64_t seed);      /* `init` op: Glorot-uniform kernels, BN identity */
+int azr_nn_set_weights(azr_engine* h, const float* flat_host, size_t count);
+int azr_nn_get_weights(azr_engine* h, float* flat_host, size_t count);
+int azr_nn_load(azr_engine* h, const char* path);          /* loadCheckpoint (alphazero_nn.cpp:189-204) */
+int azr_nn_save(azr_engine* h, const char* path);          /* saveCheckpoint (alphazero_nn.cpp:206-214) */
+/* predict / processBatchPrediction (alphazero_nn.cpp:236-267,322-349): n inputs -> softmax pi[n][43], tanh v[n] */
+int azr_nn_predict(azr_engine* h, const void* in88_host, int n, float* pi_host, float* v_host);
+
+/* ---- search: AlphaZeroMCTS / StateSimulationsStorage (alphazero_mcts.h:55-95) ---------------------------- */
+int azr_mcts_clear(azr_engine* h);   /* clearNodes (alphazero_mcts.cpp:223-227), all games */
+int azr_mcts_trim(azr_engine* h);    /* trimNodes  (alphazero_mcts.cpp:229-245), all games */
+/* AlphaZeroMCTS::simulate (alphazero_mcts.cpp:255-307) at THREADS_PER_MCTS = 1 for all G roots in lock-step:
+ * trim, expand the root if unknown, then mcts_simulations searches per game.  Finished games idle. */
+int azr_mcts_simulate(azr_engine* h);
+/* The same search split at the NN seam (predictFuture, alphazero_mcts.cpp:350-351), so a caller can supply
+ * priors/values itself: begin -> { leaves -> [evaluate] -> apply }* until *active_out == 0. */
+int azr_mcts_begin(azr_engine* h);
+int azr_mcts_leaves(azr_engine* h, void* in88_host, uint8_t* need_eval_host, int* active_out);
+int azr_mcts_apply(azr_engine* h, const float* pi_host, const float* v_host);
+/* root statistics of the last search: N[G][43]; Q,P optional */
+int azr_mcts_root_stats(azr_engine* h, uint32_t* n_host, float* q_host, float* p_host);
+/* StateSimulations::calculateMoveProbability(1.0f) (alphazero_mcts.cpp:121-149) */
+int azr_mcts_policy(azr_engine* h, float* pi_host);
+/* pickHigestWeightedMove / pickRandomWeightedMove (alphazero_mcts.cpp:379-412) on the last search's policy;
+ * sample != 0 draws with the game's own RNG stream (one rFloat). */
+int azr_mcts_pick(azr_engine* h, int sample, uint8_t* moves_host);
+
+/* ---- device-resident self-play (trainer move loop, alphazero_trainer.cpp:80-119) --------------------------- */
+/* (Re)start all G games: game g plays seeds base_seed + g, then base_seed + G + g, ... */
+int azr_selfplay_start(azr_engine* h, uint32_t base_seed);
+/* Run `passes` passes of the hot path: every pass = one tree step (backup/expand + select to the next leaf,
+ * decisions, moves, game restarts — all on device) + one batched net evaluation of the G leaves. */
+int azr_selfplay_run(azr_engine* h, int passes);
+typedef struct azr_counters {
+    uint64_t simulations;   /* completed search() descents (root expansions not counted) */
+    uint64_t evaluations;   /* net evaluations consumed (leaf + root) */
+    uint64_t levels;        /* inner-node levels visited (mean depth = levels / simulations) */
+    uint64_t decisions;     /* moves played */
+    uint64_t games_finished;
+    uint64_t samples;       /* records produced */
+    uint64_t nodes_dropped; /* expansions skipped because the node pool was full (should be 0) */
+    uint64_t errors;        /* games stopped on a rules error (should be 0) */
+} azr_counters;
+int azr_selfplay_counters(azr_engine* h, azr_counters* out);
+/* finished games' records, z filled (NNTrainDataStorage::updateValues, alphazero_nn_data.cpp:51-65) */
+int azr_samples_drain(azr_engine* h, void* rec265_host, size_t cap_records, size_t* n_out);
+/* device-side view for RCCL gathers: pointer to the packed record ring and its count; valid until the next
+ * azr_selfplay_run / azr_samples_drain */
+int azr_samples_device_view(azr_engine* h, void** dev_ptr_out, size_t* n_out);
+
+/* ---- measurement hooks (bench.py) --------------------------------------------------------------------------- */
+/* average duration in ms of the net-forward launches and of the tree-step launches over the last
+ * azr_selfplay_run, measured with HIP events on the engine's stream */
+int azr_profile_last_run(azr_engine* h, float* net_ms_avg, float* tree_ms_avg, int* launches);
+int azr_device_synchronize(azr_engine* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZR_H */
