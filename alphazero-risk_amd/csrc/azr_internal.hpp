@@ -59,8 +59,7 @@ struct NetDev {
     float* d_fold;     // folded BN: stem scale[7] shift[7]; per conv layer scale[256] shift[256]
     const float* head; // head section of d_flat
     // bf16 MFMA path
-    uint16_t* stem_wp;  // packed fragments
-    uint16_t* tower_wp; // packed fragments [2B][...]
+    void* bf16ctx;      // azr_net_bf16.hip: packed weight fragments + tower output buffer
     // activations (fp32 path)
     float* actX;       // [G][42][256]
     float* actT;       // [G][42][256]

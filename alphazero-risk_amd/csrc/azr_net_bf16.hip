@@ -1,8 +1,372 @@
-// placeholder until the MFMA tower lands
+// azr_net_bf16.hip — the residual tower of python/src/build_graph.py:63-74 as ONE persistent MFMA kernel (gfx950).
+//
+// MI355X-first design (not a per-layer conv library call):
+//   * A workgroup (8 waves, 512 threads) owns NB whole boards (NB = 1, 2 or 3 -> M = 48 / 96 / 128 GEMM rows) for the
+//     ENTIRE stem + 2B conv layers.  The boards' activations (42 x 256 bf16 each) never leave LDS: two ping-pong
+//     buffers [rows + 1 zero row][256 + 8 pad] bf16, 134 KB of the CU's 160 KB at NB = 3.  HBM sees the 88-byte
+//     inputs, the weights, and the final activation only.
+//   * Implicit GEMM per layer: M = board cells, N = 256 output channels, K = 9 taps x 256 input channels, on
+//     v_mfma_f32_16x16x32_bf16 (fp32 accumulate).  The A operand of tap (dy,dx) is the SAME LDS image read at a
+//     per-lane row offset (out-of-board neighbours read the zero row) — no im2col, no halo copies.
+//   * Waves split N (32 channels = two 16-wide tiles each), so weight fragments are private to a wave and stream
+//     global -> VGPR with no LDS staging, pre-packed on the host in exactly the lane order of the MFMA B operand
+//     (one coalesced 1-KiB global_load_dwordx4 per fragment), double-buffered 4 k-steps ahead.
+//   * Epilogue per layer in registers: folded BN (fp32 scale/shift per channel = per lane), residual add (read from
+//     the LDS image being replaced), ReLU, round-to-nearest-even bf16, written straight back into LDS.
+//   * conv_bn of the stem normalises over the board ROW (build_graph.py:68 axis=1): per-row scale/shift.
+// One barrier per layer.  The heads (1x1 convs + dense layers, 47 k MAC/board) run as a second small kernel.
+#include <string.h>
+
+#include <vector>
+
 #include "azr_internal.hpp"
+
+using namespace azr;
+
+#define HIPCHK(h, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
+            return AZR_E_HIP;                                                                   \
+        }                                                                                       \
+    } while (0)
+
 namespace azr {
-int net_bf16_alloc(azr_engine* h) { h->err = "bf16 net not built yet"; return AZR_E_STATE; }
-void net_bf16_free(azr_engine*) {}
-int net_bf16_upload(azr_engine*) { return AZR_OK; }
-int net_bf16_forward(azr_engine* h, const uint8_t*, int, int, float*, float*) { h->err = "bf16 net not built yet"; return AZR_E_STATE; }
+void launch_heads_bf16(hipStream_t st, int n, const uint16_t* X, const float* hp, float* pi, float* v);
+const float* net_head_params(azr_engine* h);
+const float* net_fold(azr_engine* h);
+}  // namespace azr
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+namespace {
+constexpr int ROWB = 528;                 // LDS bytes per activation row: 256 bf16 + 16 B pad (bank spread)
+constexpr int FROWB = 32;                 // LDS bytes per stem-feature row: 16 bf16 (13 planes + 3 zero)
+constexpr int KS_PER_TAP = 8;             // 256 input channels / 32 per MFMA
+constexpr int STEM_KS = 5;                // 9 taps x 16 channels = 144 -> 5 k-steps of 32 (last half zero)
+constexpr size_t FRAGS_PER_KSTEP = 16;    // 8 waves x 2 n-tiles, 64 lanes x 16 B each
+constexpr size_t TOWER_LAYER_HALFS = (size_t)9 * KS_PER_TAP * FRAGS_PER_KSTEP * 64 * 8;  // = 2304 * 256
+constexpr size_t STEM_HALFS = (size_t)STEM_KS * FRAGS_PER_KSTEP * 64 * 8;
+
+__host__ __device__ inline uint16_t f2bf(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
 }
+__device__ __forceinline__ uint16_t bf_rne(float f)
+{
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32, round-to-nearest-even
+    return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// setInStateTensor (alphazero_nn.cpp:31-67) for one cell/plane, from the 88-byte NNInputData image in LDS
+__device__ __forceinline__ float plane_value(const uint8_t* in88, int pos, int c)
+{
+    const uint32_t b = in88[pos];
+    const int army = b & 63, owner = b >> 6, cur = in88[42], enemy = cur == 0 ? 1 : 0;
+    const float fa = (float)army / 32.0f;
+    const float* f = reinterpret_cast<const float*>(in88 + 48);
+    switch (c) {
+    case 0: return owner == cur ? fa : 0.0f;
+    case 1: return owner == enemy ? fa : 0.0f;
+    case 2: return owner == 2 ? fa : 0.0f;
+    case 3: return f[9];
+    case 4: return f[0];
+    case 5: return f[1];
+    case 6: return f[2];
+    default: return c < 13 ? f[3 + (c - 7)] : 0.0f;
+    }
+}
+
+// byte offset (row part) of the LDS row a lane reads for board-cell info `ri` under tap (dy,dx); rows outside the
+// board (or padding rows of the last M tile) read the zero row.  ri = y | x << 4 | row << 8 (y = 15 for padding).
+__device__ __forceinline__ int tap_row(int ri, int dy, int dx, int zero_row)
+{
+    const int y = (ri & 15) + dy, x = ((ri >> 4) & 15) + dx;
+    const bool ok = (unsigned)y < 7u && (unsigned)x < 6u;
+    return ok ? (ri >> 8) + dy * 6 + dx : zero_row;
+}
+
+template <int NB>
+struct Geo {
+    static constexpr int ROWS = 42 * NB;
+    static constexpr int MT = (ROWS + 15) / 16;
+    static constexpr int BUF = (ROWS + 1) * ROWB;   // one activation buffer incl. its zero row
+    static constexpr int IN88_OFF = 2 * BUF;        // NB x 96 B of NNInputData images
+    static constexpr int LDS_BYTES = 2 * BUF + NB * 96;
+};
+
+// one 3x3 conv layer F->F: acc[mt][nt] = sum over taps, channels.  IN = LDS activation image; wp = this layer's
+// packed weights already offset to this wave's fragments ((wave * 2) * 64 + lane) in s16x8 units.
+template <int MT>
+__device__ __forceinline__ void conv_tower_layer(const uint8_t* IN, const s16x8* __restrict__ wp, f32x4 (&acc)[MT][2],
+                                                 const int (&rinfo)[MT], int g16, int zero_row)
+{
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) { acc[mt][0] = f32x4{0, 0, 0, 0}; acc[mt][1] = f32x4{0, 0, 0, 0}; }
+    s16x8 bq[2][4][2];
+    constexpr size_t KSTRIDE = FRAGS_PER_KSTEP * 64;  // s16x8 units between consecutive k-steps
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) { bq[0][kk][0] = wp[kk * KSTRIDE]; bq[0][kk][1] = wp[kk * KSTRIDE + 64]; }
+    for (int tap = 0; tap < 9; tap++) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        int aoff[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) aoff[mt] = tap_row(rinfo[mt], dy, dx, zero_row) * ROWB + g16;
+        const s16x8* wt = wp + (size_t)tap * KS_PER_TAP * KSTRIDE;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            // prefetch the next chunk of 4 k-steps (second half of this tap, or first half of the next tap)
+            if (half == 0 || tap < 8) {
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const s16x8* src = wt + (size_t)((half + 1) * 4 + kk) * KSTRIDE;
+                    bq[half ^ 1][kk][0] = src[0];
+                    bq[half ^ 1][kk][1] = src[64];
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int ks = half * 4 + kk;
+                s16x8 a[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) a[mt] = *reinterpret_cast<const s16x8*>(IN + aoff[mt] + ks * 64);
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[mt]),
+                                                                         __builtin_bit_cast(bf16x8, bq[half][kk][0]), acc[mt][0], 0, 0, 0);
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[mt]),
+                                                                         __builtin_bit_cast(bf16x8, bq[half][kk][1]), acc[mt][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(512, 2) void k_tower_bf16(const uint8_t* __restrict__ in88, int in_stride, int n,
+                                                       const uint16_t* __restrict__ stem_wp,
+                                                       const uint16_t* __restrict__ tower_wp,
+                                                       const float* __restrict__ fold, int blocks,
+                                                       uint16_t* __restrict__ out)
+{
+    using G = Geo<NB>;
+    constexpr int ROWS = G::ROWS, MT = G::MT;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t* bufX = lds;
+    uint8_t* bufT = lds + G::BUF;
+    uint8_t* in_l = lds + G::IN88_OFF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, g = lane >> 4;
+    const int board0 = blockIdx.x * NB;
+
+    // ---- stage the NNInputData images, zero the zero rows and the stem feature image
+    for (int i = tid; i < NB * 96; i += 512) {
+        const int b = i / 96, o = i % 96;
+        in_l[i] = (board0 + b < n && o < 88) ? in88[(size_t)(board0 + b) * in_stride + o] : (uint8_t)0;
+    }
+    for (int i = tid; i < ROWB / 4; i += 512) {
+        reinterpret_cast<uint32_t*>(bufX + ROWS * ROWB)[i] = 0;
+        reinterpret_cast<uint32_t*>(bufT + ROWS * ROWB)[i] = 0;
+    }
+    __syncthreads();
+    // stem features: bufT as [ROWS + 1][16] bf16 (row ROWS = zero row); planes 13..15 are zero
+    for (int i = tid; i < (ROWS + 1) * 16; i += 512) {
+        const int r = i >> 4, c = i & 15;
+        float v = 0.0f;
+        if (r < ROWS) v = plane_value(in_l + (r / 42) * 96, r % 42, c);
+        reinterpret_cast<uint16_t*>(bufT)[i] = bf_rne(v);
+    }
+    __syncthreads();
+
+    // ---- per-lane geometry of the rows this lane feeds as MFMA A operand (row = mt*16 + m)
+    int rinfo[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        const int r = mt * 16 + m;
+        const int pos = r % 42, y = pos / 6, x = pos % 6;
+        rinfo[mt] = r < ROWS ? (y | (x << 4) | (r << 8)) : (15 | (15 << 4) | (ROWS << 8));
+    }
+    f32x4 acc[MT][2];
+
+    // ---- stem: 3x3 conv 13 -> 256, two taps per 32-deep k-step (tap slot = 2*ks + (g >> 1), channels (g & 1)*8 ..)
+    {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) { acc[mt][0] = f32x4{0, 0, 0, 0}; acc[mt][1] = f32x4{0, 0, 0, 0}; }
+        const s16x8* wp = reinterpret_cast<const s16x8*>(stem_wp) + (size_t)(wave * 2) * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < STEM_KS; ks++) {
+            const int tap = 2 * ks + (g >> 1);
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const s16x8 b0 = wp[(size_t)ks * FRAGS_PER_KSTEP * 64], b1 = wp[(size_t)ks * FRAGS_PER_KSTEP * 64 + 64];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const int row = tap < 9 ? tap_row(rinfo[mt], dy, dx, ROWS) : ROWS;
+                const s16x8 a = *reinterpret_cast<const s16x8*>(bufT + row * FROWB + (g & 1) * 16);
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b0), acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b1), acc[mt][1], 0, 0, 0);
+            }
+        }
+        // conv_bn over the board row + ReLU -> bufX   (C/D layout: col = lane & 15, row = (lane >> 4)*4 + j)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r = mt * 16 + g * 4 + j;
+                if (r < ROWS) {
+                    const int y = (r % 42) / 6;
+                    const float sc = fold[y], sh = fold[7 + y];
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++) {
+                        const int co = wave * 32 + nt * 16 + m;
+                        float v = fmaf(acc[mt][nt][j], sc, sh);
+                        reinterpret_cast<uint16_t*>(bufX + r * ROWB)[co] = bf_rne(v > 0.0f ? v : 0.0f);
+                    }
+                }
+            }
+    }
+    __syncthreads();
+
+    // ---- residual tower: 2 conv layers per block, activations resident in LDS
+    const int g16 = g * 16;
+    for (int layer = 0; layer < 2 * blocks; layer++) {
+        const bool second = layer & 1;
+        const uint8_t* IN = second ? bufT : bufX;
+        uint8_t* OUT = second ? bufX : bufT;
+        const s16x8* wp = reinterpret_cast<const s16x8*>(tower_wp + (size_t)layer * TOWER_LAYER_HALFS) + (size_t)(wave * 2) * 64 + lane;
+        conv_tower_layer<MT>(IN, wp, acc, rinfo, g16, ROWS);
+        const float* fs = fold + 14 + (size_t)layer * 2 * NF;
+        float sc[2], sh[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) { sc[nt] = fs[wave * 32 + nt * 16 + m]; sh[nt] = fs[NF + wave * 32 + nt * 16 + m]; }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r = mt * 16 + g * 4 + j;
+                if (r < ROWS) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++) {
+                        const int co = wave * 32 + nt * 16 + m;
+                        uint16_t* o = reinterpret_cast<uint16_t*>(OUT + r * ROWB) + co;
+                        float v = fmaf(acc[mt][nt][j], sc[nt], sh[nt]);
+                        if (second) v += bf2f(*o);  // shortcut: OUT still holds the block's input at this element
+                        *o = bf_rne(v > 0.0f ? v : 0.0f);
+                    }
+                }
+            }
+        __syncthreads();
+    }
+
+    // ---- final activation -> HBM (bf16 [board][42][256]) for the heads kernel
+    for (int i = tid; i < ROWS * 32; i += 512) {
+        const int r = i >> 5, seg = i & 31;
+        if (board0 + r / 42 < n) {
+            const uint4 v = *reinterpret_cast<const uint4*>(bufX + r * ROWB + seg * 16);
+            *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)board0 * 42 + r) * 512 + seg * 16) = v;
+        }
+    }
+}
+
+struct Bf16Net {
+    uint16_t* stem_wp = nullptr;
+    uint16_t* tower_wp = nullptr;
+    uint16_t* act = nullptr;  // [G][42][256] bf16 tower output
+};
+Bf16Net* bn(azr_engine* h) { return reinterpret_cast<Bf16Net*>(h->net.bf16ctx); }
+}  // namespace
+
+namespace azr {
+
+int net_bf16_alloc(azr_engine* h)
+{
+    Bf16Net* x = new Bf16Net();
+    h->net.bf16ctx = x;
+    const int B = h->net.blocks;
+    HIPCHK(h, hipMalloc((void**)&x->stem_wp, STEM_HALFS * 2));
+    HIPCHK(h, hipMalloc((void**)&x->tower_wp, (size_t)2 * B * TOWER_LAYER_HALFS * 2));
+    HIPCHK(h, hipMalloc((void**)&x->act, (size_t)h->d.G * NPOS * NF * 2));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<1>::LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<2>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<2>::LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<3>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<3>::LDS_BYTES));
+    return AZR_OK;
+}
+
+void net_bf16_free(azr_engine* h)
+{
+    if (!h->net.bf16ctx) return;
+    Bf16Net* x = bn(h);
+    if (x->stem_wp) hipFree(x->stem_wp);
+    if (x->tower_wp) hipFree(x->tower_wp);
+    if (x->act) hipFree(x->act);
+    delete x;
+    h->net.bf16ctx = nullptr;
+}
+
+// pack the HWIO fp32 kernels of the AZRW vector into MFMA B-operand fragment order (bf16, RNE):
+// fragment (layer, tap, ks, wave, nt), lane l, element j  <-  W[tap][ci = ks*32 + 8*(l>>4) + j][co = wave*32 + nt*16 + (l&15)]
+int net_bf16_upload(azr_engine* h)
+{
+    Bf16Net* x = bn(h);
+    const int B = h->net.blocks;
+    const float* flat = h->flat.data();
+    std::vector<uint16_t> stem(STEM_HALFS, 0), tower((size_t)2 * B * TOWER_LAYER_HALFS);
+    for (int ks = 0; ks < STEM_KS; ks++)
+        for (int w = 0; w < 8; w++)
+            for (int nt = 0; nt < 2; nt++)
+                for (int l = 0; l < 64; l++)
+                    for (int j = 0; j < 8; j++) {
+                        const int g = l >> 4, tap = 2 * ks + (g >> 1), ch = (g & 1) * 8 + j, co = w * 32 + nt * 16 + (l & 15);
+                        float v = (tap < 9 && ch < 13) ? flat[((size_t)tap * 13 + ch) * NF + co] : 0.0f;
+                        stem[((((size_t)ks * 8 + w) * 2 + nt) * 64 + l) * 8 + j] = f2bf(v);
+                    }
+    const size_t layer_floats = (size_t)9 * NF * NF + 4 * NF;
+    const float* t0 = flat + 9 * 13 * NF + 28;
+    for (int L = 0; L < 2 * B; L++) {
+        const float* W = t0 + (size_t)L * layer_floats;
+        uint16_t* dst = tower.data() + (size_t)L * TOWER_LAYER_HALFS;
+        for (int tap = 0; tap < 9; tap++)
+            for (int ks = 0; ks < 8; ks++)
+                for (int w = 0; w < 8; w++)
+                    for (int nt = 0; nt < 2; nt++)
+                        for (int l = 0; l < 64; l++) {
+                            const int ci0 = ks * 32 + 8 * (l >> 4), co = w * 32 + nt * 16 + (l & 15);
+                            uint16_t* d = dst + (((((size_t)tap * 8 + ks) * 8 + w) * 2 + nt) * 64 + l) * 8;
+                            for (int j = 0; j < 8; j++) d[j] = f2bf(W[((size_t)tap * NF + ci0 + j) * NF + co]);
+                        }
+    }
+    HIPCHK(h, hipMemcpyAsync(x->stem_wp, stem.data(), stem.size() * 2, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(x->tower_wp, tower.data(), tower.size() * 2, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return AZR_OK;
+}
+
+int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v)
+{
+    Bf16Net* x = bn(h);
+    const float* fold = net_fold(h);
+    const int B = h->net.blocks;
+    // boards per workgroup: fill the 256 CUs first, then grow the M tile
+    if (n <= 256) {
+        hipLaunchKernelGGL(k_tower_bf16<1>, dim3(n), dim3(512), Geo<1>::LDS_BYTES, h->stream, d_in88, in_stride, n,
+                           x->stem_wp, x->tower_wp, fold, B, x->act);
+    } else if (n <= 512) {
+        hipLaunchKernelGGL(k_tower_bf16<2>, dim3((n + 1) / 2), dim3(512), Geo<2>::LDS_BYTES, h->stream, d_in88, in_stride, n,
+                           x->stem_wp, x->tower_wp, fold, B, x->act);
+    } else {
+        hipLaunchKernelGGL(k_tower_bf16<3>, dim3((n + 2) / 3), dim3(512), Geo<3>::LDS_BYTES, h->stream, d_in88, in_stride, n,
+                           x->stem_wp, x->tower_wp, fold, B, x->act);
+    }
+    launch_heads_bf16(h->stream, n, x->act, net_head_params(h), d_pi, d_v);
+    HIPCHK(h, hipGetLastError());
+    return AZR_OK;
+}
+
+}  // namespace azr

@@ -1,0 +1,65 @@
+"""Sharding of self-play over ranks (one process per GPU) and the one exchange step of a learn iteration.
+
+Games are independent units: rank r plays its own G games with disjoint seed streams and there is NO
+data-path collective during self-play (reference: one self-play thread per GPU, alphazero_trainer.cpp:41-57).
+The only exchange is the gather of finished (s, pi, z) records (reference: trainStorage.extend per GPU,
+alphazero_trainer.cpp:59-62) — here an all_gather over torch.distributed (backend "nccl" = RCCL over xGMI on
+the GPU box, "gloo" in the CPU tests).
+"""
+import numpy as np
+
+RECORD_BYTES = 265
+SEED_STRIDE = 1 << 24  # rank r draws seeds base + r * 2^24 + game_no * G + g  (game_no * G + g < 2^24)
+
+
+def rank_base_seed(base_seed, rank):
+    """disjoint per-rank seed ranges for azr_selfplay_start"""
+    return (int(base_seed) + int(rank) * SEED_STRIDE) & 0xFFFFFFFF
+
+
+def gather_records(records, dist=None, device=None):
+    """all ranks contribute a uint8 tensor [n_r, 265]; every rank gets the concatenation in rank order.
+    Padded all_gather: counts first, then buffers padded to the maximum count."""
+    import torch
+
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return records
+    world = dist.get_world_size()
+    dev = records.device if device is None else device
+    n = torch.tensor([records.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    buf = torch.zeros((cap, RECORD_BYTES), dtype=torch.uint8, device=dev)
+    buf[:records.shape[0]] = records.to(dev)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+
+
+def reduce_counters(counters, dist=None, device="cpu"):
+    """sum the per-rank counter dicts (reference: GameResults::add, game.cpp:303-307)"""
+    import torch
+
+    keys = sorted(counters)
+    t = torch.tensor([counters[k] for k in keys], dtype=torch.int64, device=device)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return {k: int(v) for k, v in zip(keys, t.tolist())}
+
+
+def device_records_to_torch(ptr, n, device):
+    """copy n packed records from the engine's device ring (raw pointer) into a torch uint8 tensor on `device`"""
+    import ctypes as C
+
+    import torch
+
+    out = torch.empty((n, RECORD_BYTES), dtype=torch.uint8, device=device)
+    if n:
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        rc = hip.hipMemcpy(C.c_void_p(out.data_ptr()), C.c_void_p(ptr), n * RECORD_BYTES, 3)  # hipMemcpyDeviceToDevice
+        if rc:
+            raise RuntimeError(f"hipMemcpy failed: {rc}")
+    return out

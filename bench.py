@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py — MCTS simulations/s of device-resident AlphaZero-Risk self-play on MI355X.
+
+Workload (BASELINE.json configs[1]): 256 concurrent self-play games per GPU, 100 MCTS simulations per move,
+random-init 20-block / 256-filter net, bf16 MFMA contractions with fp32 accumulation.  One "step" = one pass of
+the hot path over the batch of games: a tree step (expand + backup of the previous leaves, PUCT descent to the
+next leaves — and, when a search completes, the move, the record and possibly a game restart — for all G games)
+followed by one batched net evaluation of the G leaves.  Everything is resident in HBM; nothing crosses PCIe in
+the timed region except the final counters.  Multi-GPU: one process per GPU, games sharded, no data-path
+collective; one RCCL all_gather of the finished (s, pi, z) records closes the timed region (weak scaling).
+
+    python bench.py [--gpus N --steps K --warmup W] [--games 256 --sims 100 --blocks 20 --dtype bf16]
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_SIM = {20: 2 * 797_976_348, 5: 2 * 200_288_028}  # valid (un-padded) taps only
+PEAK_BF16 = 2.5e15   # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_F32 = 157.3e12  # fp32 vector/matrix
+
+
+def flop_per_sim(blocks):
+    if blocks in FLOP_PER_SIM:
+        return FLOP_PER_SIM[blocks]
+    mac = 304 * 13 * 256 + blocks * 2 * 304 * 256 * 256 + 46_876
+    return 2 * mac
+
+
+def cpu_baseline(blocks, sims, seconds_budget=25.0):
+    """the oracle (CPU port of the reference path, t = 1, one game per thread, fp32 CPU net) on this box's host
+    cores, bounded sample: one decision (sims simulations + root expansion) per thread"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import azr_testlib as T
+
+    orc = T.oracle()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(cores, 64))
+    flat = T.make_net_flat(blocks)
+    net = T.OrcNet(blocks, flat.ctypes.data_as(T.f32p))
+    cfg = T.default_settings(mcts_simulations=sims)
+    orc.orc_bench_selfplay.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]
+    s, e, sec = C.c_uint64(), C.c_uint64(), C.c_double()
+    # calibrate with a short search so the real sample stays inside the budget
+    cal = T.default_settings(mcts_simulations=4)
+    orc.orc_bench_selfplay(C.byref(cal), C.byref(net), 20260001, threads, 1, C.byref(s), C.byref(e), C.byref(sec))
+    per_eval = sec.value / max(1, e.value / threads)
+    decisions = max(1, int(seconds_budget / (per_eval * (sims + 1))))
+    decisions = min(decisions, 4)
+    orc.orc_bench_selfplay(C.byref(cfg), C.byref(net), 20260001, threads, decisions, C.byref(s), C.byref(e),
+                           C.byref(sec))
+    return {"value": s.value / sec.value, "unit": "MCTS simulations/s", "cores": threads, "kind": "port",
+            "sample": f"{threads} games (one per thread, t=1), {decisions} decision(s) x {sims} sims each, "
+                      f"{blocks}-block fp32 CPU net, {sec.value:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--games", type=int, default=256, help="concurrent games per GPU")
+    ap.add_argument("--sims", type=int, default=100)
+    ap.add_argument("--blocks", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path is the only path (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = importlib.import_module("alphazero-risk_amd")
+    from importlib import import_module
+    shard = import_module("alphazero-risk_amd.shard")
+    eng = pkg.Engine(a.games, blocks=a.blocks, sims=a.sims, dtype=pkg.NET_BF16 if a.dtype == "bf16" else pkg.NET_F32,
+                     device=local)
+    eng.init_random(20260002)
+    eng.selfplay_start(shard.rank_base_seed(20260001, rank))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.selfplay_run(a.warmup)
+    eng.drain(1)  # reset the record ring
+    c0 = eng.counters()
+    barrier()
+    t0 = time.perf_counter()
+    eng.selfplay_run(a.steps)          # EXACTLY K passes (synchronises at the end)
+    ptr, nrec = eng.samples_device_view()
+    recs = shard.device_records_to_torch(ptr, nrec, dev)
+    allrecs = shard.gather_records(recs, dist if world > 1 else None)   # the path's one exchange step
+    barrier()
+    dt = time.perf_counter() - t0
+    c1 = eng.counters()
+    prof = eng.profile_last_run()
+
+    delta = {k: c1[k] - c0[k] for k in c1}
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tot = torch.tensor([delta["simulations"], delta["evaluations"], delta["levels"], delta["decisions"],
+                        delta["games_finished"], delta["samples"], delta["errors"], delta["nodes_dropped"]],
+                       dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    sims, evals, levels, decisions, games, samples, errors, dropped = [int(x) for x in tot.tolist()]
+
+    if rank == 0:
+        fps = flop_per_sim(a.blocks)
+        net_s = prof["net_ms"] * 1e-3
+        achieved = a.games * fps / net_s if net_s > 0 else 0.0
+        peak = PEAK_BF16 if a.dtype == "bf16" else PEAK_F32
+        out = {
+            "metric": "MCTS simulations/s", "value": sims / dt, "unit": "simulations/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"{a.games} concurrent self-play games/GPU x {a.sims} MCTS sims/move, "
+                                   f"{a.blocks}-block 256-filter random-init net (BASELINE configs[1])",
+                       "games_per_gpu": a.games, "sims_per_move": a.sims, "blocks": a.blocks,
+                       "parallelism": f"games sharded x{world}, no data-path collective; 1 all_gather of records"},
+            "self_play_games_per_s": games / dt, "decisions_per_s": decisions / dt,
+            "net_evals_per_s": evals / dt, "mean_depth": levels / max(1, sims),
+            "games_finished": games, "records_gathered": int(allrecs.shape[0]), "errors": errors,
+            "nodes_dropped": dropped,
+            "roofline": {"bound": "mfma", "kernel": "k_tower_bf16 + k_heads (one net forward of G leaves)"
+                         if a.dtype == "bf16" else "fp32 conv chain", "achieved": achieved / 1e12,
+                         "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "flop_per_launch": a.games * fps, "avg_launch_ms": prof["net_ms"],
+                         "tree_step_avg_ms": prof["tree_ms"], "timed_launches": prof["launches"], "traffic": None},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.blocks, a.sims)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1487,3 +1487,41 @@ int orc_selfplay_game(const orc_settings* cfg, uint32_t seed, orc_eval_fn eval, 
     orc_mcts_destroy(m);
     return n;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * cpu_baseline leg of bench.py: `threads` independent self-play games (one per thread, t = 1, fp32 CPU net),
+ * each playing `decisions` decisions of the trainer's move loop from newGame.  Returns total completed
+ * simulations and wall seconds.
+ * ---------------------------------------------------------------------------------------------- */
+#include <time.h>
+typedef struct { const orc_settings* cfg; const orc_net* net; uint32_t seed; int decisions; uint64_t sims, evals; } bench_job;
+static void* bench_thread(void* a)
+{
+    bench_job* j = (bench_job*)a;
+    uint8_t* rec = (uint8_t*)malloc((size_t)265 * (size_t)(j->decisions + 1));
+    int st, rounds;
+    orc_selfplay_game(j->cfg, j->seed, orc_net_eval, (void*)j->net, rec, j->decisions + 1, &st, &rounds, NULL,
+                      j->decisions, &j->sims, &j->evals);
+    free(rec);
+    return NULL;
+}
+int orc_bench_selfplay(const orc_settings* cfg, const orc_net* net, uint32_t base_seed, int threads, int decisions,
+                       uint64_t* sims, uint64_t* evals, double* seconds)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t th[256];
+    bench_job jobs[256];
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int t = 0; t < threads; t++) {
+        jobs[t] = (bench_job){cfg, net, base_seed + (uint32_t)t, decisions, 0, 0};
+        pthread_create(&th[t], NULL, bench_thread, &jobs[t]);
+    }
+    uint64_t s = 0, e = 0;
+    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); s += jobs[t].sims; e += jobs[t].evals; }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    *sims = s; *evals = e;
+    *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    return 0;
+}

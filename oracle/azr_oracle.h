@@ -144,6 +144,10 @@ int orc_selfplay_game(const orc_settings* cfg, uint32_t seed, orc_eval_fn eval, 
                       uint8_t* rec265, int cap, int* status, int* rounds, uint8_t* moves_out, int max_decisions,
                       uint64_t* sims_out, uint64_t* evals_out);
 
+/* bench.py cpu_baseline: `threads` games in parallel, `decisions` decisions each, fp32 CPU net */
+int orc_bench_selfplay(const orc_settings* cfg, const orc_net* net, uint32_t base_seed, int threads, int decisions,
+                       uint64_t* sims, uint64_t* evals, double* seconds);
+
 /* deterministic integer-hash stub "net" shared by oracle-side tests: pi_i in (0.5,1.5)/sum, v in (-1,1) */
 void orc_hash_eval(void* ctx, const uint8_t* in88, float* pi43, float* v);
 /* uniform stub: every prior identical (forces the unordered_map tie-break path), v = 0 */

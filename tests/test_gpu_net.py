@@ -62,3 +62,52 @@ def test_checkpoint_roundtrip(tmp_path):
     eng.load(path)
     assert (eng.get_weights() == w).all()
     eng.close()
+
+
+@pytest.mark.parametrize("n,blocks", [(48, 2), (300, 2), (600, 1), (16, 20)])
+def test_bf16_mfma_tower_matches_fp32_oracle(orc, n, blocks):
+    """bf16 MFMA path (bf16 weights and inter-layer activations, fp32 accumulate/epilogue) vs the fp32 oracle.
+    Stated tolerance: max |dpi| <= 2e-2, max |dv| <= 2e-2; typical error is ~1e-3.
+    n selects the 1-, 2- and 3-boards-per-workgroup variants (M = 48 / 96 / 128)."""
+    P = pkg()
+    base = sample_inputs(64)
+    x = np.concatenate([base] * ((n + 63) // 64))[:n].copy()
+    flat = T.make_net_flat(blocks, seed=3, perturb_bn=True)
+    eng = P.Engine(n, blocks=blocks, sims=1, dtype=P.NET_BF16, node_capacity=64)
+    eng.set_weights(flat)
+    pi, v = eng.predict(x)
+    m = min(n, 64)
+    rpi, rv = oracle_forward(orc, flat, blocks, x[:m])
+    dpi, dv = np.abs(pi[:m] - rpi).max(), np.abs(v[:m] - rv).max()
+    print(f"bf16 n={n} B={blocks}: max|dpi|={dpi:.2e} max|dv|={dv:.2e}")
+    assert dpi <= 2e-2 and dv <= 2e-2, (dpi, dv)
+    assert np.allclose(pi.sum(1), 1.0, atol=1e-5)
+    # identical inputs in different slots / workgroup shapes give identical bits (batch invariance)
+    if n > 64:
+        assert (pi[:64].view(np.uint32) == pi[64:128].view(np.uint32)).all() or n < 128
+    p1, v1 = eng.predict(x[:3])
+    assert (p1.view(np.uint32) == pi[:3].view(np.uint32)).all() and (v1 == v[:3]).all()
+    eng.close()
+
+
+def test_selfplay_bf16_runs_clean():
+    """device-resident self-play on the bf16 net: counters consistent, no rule errors, records well-formed"""
+    P = pkg()
+    G, S = 64, 16
+    eng = P.Engine(G, blocks=2, sims=S, dtype=P.NET_BF16, max_game_rounds=34)
+    eng.init_random(1)
+    eng.selfplay_start(77)
+    for _ in range(200):
+        eng.selfplay_run(128)
+        if eng.counters()["games_finished"] >= G // 2:
+            break
+    c = eng.counters()
+    assert c["errors"] == 0 and c["nodes_dropped"] == 0 and c["games_finished"] >= G // 2
+    assert c["simulations"] >= c["decisions"] * S * 0.99
+    r = eng.drain()
+    assert len(r) == c["samples"] and len(r) > 0
+    pi = r[:, 93:265].copy().view(np.float32).reshape(-1, 43)
+    z = r[:, 89:93].copy().view(np.float32).reshape(-1)
+    assert np.allclose(pi.sum(1), 1.0, atol=1e-4) and set(np.unique(z)) <= {-1.0, 0.0, 1.0}
+    assert set(np.unique(r[:, 0])) <= {0, 1}
+    eng.close()

@@ -1,0 +1,59 @@
+"""CPU, world_size 2 over gloo: the N>1 path of bench.py — disjoint per-rank seed streams, the padded all_gather of
+(s, pi, z) records and the counter reduction (alphazero-risk_amd/shard.py)."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    shard = importlib.import_module("alphazero-risk_amd.shard")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(100 + rank)
+    n = 5 + 7 * rank  # ragged counts, rank 0 smaller than rank 1
+    recs = torch.from_numpy(rng.integers(0, 256, (n, 265), dtype=np.uint8))
+    allr = shard.gather_records(recs, dist)
+    empty = shard.gather_records(torch.zeros((0, 265), dtype=torch.uint8) if rank == 0 else recs, dist)
+    tot = shard.reduce_counters({"simulations": 10 * (rank + 1), "games_finished": rank}, dist)
+    q.put((rank, recs.numpy(), allr.numpy(), empty.shape[0], tot, shard.rank_base_seed(20260001, rank)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_records_world2_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    want = np.concatenate([res[0][1], res[1][1]])
+    for r in range(world):
+        assert (res[r][2] == want).all()          # every rank holds the rank-ordered concatenation
+        assert res[r][3] == len(res[1][1])        # an empty shard contributes nothing
+        assert res[r][4] == {"simulations": 30, "games_finished": 1}
+    # seed ranges of different ranks cannot collide for < 2^24 games per slot-stream
+    assert res[1][5] - res[0][5] == 1 << 24
