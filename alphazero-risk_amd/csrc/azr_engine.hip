@@ -523,7 +523,7 @@ extern "C" int azr_engine_create(const azr_settings* s, azr_engine** out)
     h->cfg = *s;
     h->mode = 0;
     h->weights_set = false;
-    h->prof_net_ms = h->prof_tree_ms = 0;
+    h->prof_net_ms = h->prof_tree_ms = h->prof_tower_ms = 0;
     h->prof_launches = 0;
     *out = h;
     HIPCHK(h, hipSetDevice(s->device));
@@ -879,7 +879,7 @@ extern "C" int azr_selfplay_run(azr_engine* h, int passes)
     if (!h->weights_set) { h->err = "azr_selfplay_run: no weights"; return AZR_E_STATE; }
     const int PROF_MAX = 512;  // launches timed with events (spread over the run)
     const int nprof = std::min(passes, PROF_MAX);
-    while ((int)h->ev.size() < 3 * PROF_MAX) {
+    while ((int)h->ev.size() < 5 * PROF_MAX) {
         hipEvent_t e;
         HIPCHK(h, hipEventCreate(&e));
         h->ev.push_back(e);
@@ -891,18 +891,24 @@ extern "C" int azr_selfplay_run(azr_engine* h, int passes)
         if (prof) HIPCHK(h, hipEventRecord(h->ev[3 * k + 0], h->stream));
         LAUNCH(h, k_tree_step<true>, h->d);
         if (prof) HIPCHK(h, hipEventRecord(h->ev[3 * k + 1], h->stream));
+        h->pe_tower0 = prof ? h->ev[3 * PROF_MAX + 2 * k] : nullptr;
+        h->pe_tower1 = prof ? h->ev[3 * PROF_MAX + 2 * k + 1] : nullptr;
         int rc = net_forward(h, h->d.leaf_in, LEAF_STRIDE, h->d.G, h->d.net_pi, h->d.net_v);
+        h->pe_tower0 = h->pe_tower1 = nullptr;
         if (rc) return rc;
         if (prof) { HIPCHK(h, hipEventRecord(h->ev[3 * k + 2], h->stream)); k++; }
     }
     SYNC(h);
-    double tn = 0, tt = 0;
+    double tn = 0, tt = 0, tw = 0;
+    const bool tower_timed = h->cfg.net_dtype == AZR_NET_BF16;
     for (int i = 0; i < k; i++) {
-        float a = 0, b = 0;
+        float a = 0, b = 0, c = 0;
         HIPCHK(h, hipEventElapsedTime(&a, h->ev[3 * i + 0], h->ev[3 * i + 1]));
         HIPCHK(h, hipEventElapsedTime(&b, h->ev[3 * i + 1], h->ev[3 * i + 2]));
-        tt += a; tn += b;
+        if (tower_timed) HIPCHK(h, hipEventElapsedTime(&c, h->ev[3 * PROF_MAX + 2 * i], h->ev[3 * PROF_MAX + 2 * i + 1]));
+        tt += a; tn += b; tw += c;
     }
+    h->prof_tower_ms = k ? (float)(tw / k) : 0;
     h->prof_launches = k;
     h->prof_tree_ms = k ? (float)(tt / k) : 0;
     h->prof_net_ms = k ? (float)(tn / k) : 0;
@@ -912,7 +918,8 @@ extern "C" int azr_selfplay_run(azr_engine* h, int passes)
 extern "C" int azr_profile_last_run(azr_engine* h, float* net_ms, float* tree_ms, int* launches)
 {
     if (!h) return AZR_E_BAD_HANDLE;
-    if (net_ms) *net_ms = h->prof_net_ms;
+    // net_ms: the dominant kernel alone (k_tower_bf16) when the bf16 path is active, else the whole fp32 forward
+    if (net_ms) *net_ms = h->prof_tower_ms > 0 ? h->prof_tower_ms : h->prof_net_ms;
     if (tree_ms) *tree_ms = h->prof_tree_ms;
     if (launches) *launches = h->prof_launches;
     return AZR_OK;

@@ -77,7 +77,8 @@ struct azr_engine {
     int mode;                     // 0 rules only / stepwise, 2 self-play
     // profiling of the last azr_selfplay_run
     std::vector<hipEvent_t> ev;
-    float prof_net_ms, prof_tree_ms;
+    float prof_net_ms, prof_tree_ms, prof_tower_ms;
+    hipEvent_t pe_tower0 = nullptr, pe_tower1 = nullptr;  // when set, the net records these around its dominant kernel
     int prof_launches;
     bool weights_set;
 };

@@ -3,7 +3,7 @@
 // MI355X-first design (not a per-layer conv library call):
 //   * A workgroup (8 waves, 512 threads) owns NB whole boards (NB = 1, 2 or 3 -> M = 48 / 96 / 128 GEMM rows) for the
 //     ENTIRE stem + 2B conv layers.  The boards' activations (42 x 256 bf16 each) never leave LDS: two ping-pong
-//     buffers [rows + 1 zero row][256 + 8 pad] bf16, 134 KB of the CU's 160 KB at NB = 3.  HBM sees the 88-byte
+//     buffers [rows + 1 zero row][256 + 16 pad] bf16, 138 KB of the CU's 160 KB at NB = 3.  HBM sees the 88-byte
 //     inputs, the weights, and the final activation only.
 //   * Implicit GEMM per layer: M = board cells, N = 256 output channels, K = 9 taps x 256 input channels, on
 //     v_mfma_f32_16x16x32_bf16 (fp32 accumulate).  The A operand of tap (dy,dx) is the SAME LDS image read at a
@@ -43,7 +43,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
-constexpr int ROWB = 528;                 // LDS bytes per activation row: 256 bf16 + 16 B pad (bank spread)
+constexpr int ROWB = 544;                 // LDS bytes per activation row: 256 bf16 + 32 B pad: 16-B slot = (2*row + kgroup) mod 16 -> ds_read_b128 lane groups conflict-free
 constexpr int FROWB = 32;                 // LDS bytes per stem-feature row: 16 bf16 (13 planes + 3 zero)
 constexpr int KS_PER_TAP = 8;             // 256 input channels / 32 per MFMA
 constexpr int STEM_KS = 5;                // 9 taps x 16 channels = 144 -> 5 k-steps of 32 (last half zero)
@@ -103,50 +103,81 @@ struct Geo {
     static constexpr int LDS_BYTES = 2 * BUF + NB * 96;
 };
 
-// one 3x3 conv layer F->F: acc[mt][nt] = sum over taps, channels.  IN = LDS activation image; wp = this layer's
-// packed weights already offset to this wave's fragments ((wave * 2) * 64 + lane) in s16x8 units.
-template <int MT>
-__device__ __forceinline__ void conv_tower_layer(const uint8_t* IN, const s16x8* __restrict__ wp, f32x4 (&acc)[MT][2],
-                                                 const int (&rinfo)[MT], int g16, int zero_row)
+// One 3x3 conv layer F->F: acc[mt][nt] = sum over 9 taps x 256 channels (72 k-steps of 32).
+// Weight fragments come from a RING of RING k-steps held in VGPRs that never drains: the packed tower weights of
+// all layers are one contiguous stream in exactly consumption order, so slot (k-step % RING) is refilled with the
+// k-step RING ahead right after its MFMAs issue — also across layer boundaries, where the epilogue + barrier then
+// overlap the next layer's weight latency.  `wcur` = this lane's pointer to the fragment of the current k-step.
+constexpr size_t KSTRIDE = FRAGS_PER_KSTEP * 64;  // s16x8 units between consecutive k-steps
+constexpr int MAX_RING = 16;
+
+// ring depth in taps (8 k-steps each): the 1-board tile has VGPRs to spare and needs the most bytes in flight
+template <int NB> struct RingTaps { static constexpr int value = NB == 1 ? 2 : 1; };
+
+// one tap = 8 k-steps against ring slots SB .. SB+7
+template <int MT, int RT, int SB>
+__device__ __forceinline__ void conv_tap(const uint8_t* IN, int tap, const s16x8* __restrict__& wcur, s16x8 (&bq)[RT * 8][2],
+                                         f32x4 (&acc)[MT][2], s16x8 (&a)[2][MT], int (&aoff)[MT], const int (&rinfo)[MT],
+                                         int g16, int zero_row)
+{
+    const int ntap = tap < 8 ? tap + 1 : 8;
+    const int ndy = ntap / 3 - 1, ndx = ntap % 3 - 1;
+    int noff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) noff[mt] = tap_row(rinfo[mt], ndy, ndx, zero_row) * ROWB + g16;
+#pragma unroll
+    for (int ks = 0; ks < KS_PER_TAP; ks++) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+            a[nxt][mt] = ks < KS_PER_TAP - 1 ? *reinterpret_cast<const s16x8*>(IN + aoff[mt] + (ks + 1) * 64)
+                                             : *reinterpret_cast<const s16x8*>(IN + noff[mt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[cur][mt]),
+                                                                 __builtin_bit_cast(bf16x8, bq[SB + ks][0]), acc[mt][0], 0, 0, 0);
+            acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[cur][mt]),
+                                                                 __builtin_bit_cast(bf16x8, bq[SB + ks][1]), acc[mt][1], 0, 0, 0);
+        }
+        bq[SB + ks][0] = wcur[RT * 8 * KSTRIDE];
+        bq[SB + ks][1] = wcur[RT * 8 * KSTRIDE + 64];
+        wcur += KSTRIDE;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) aoff[mt] = noff[mt];
+}
+
+// One 3x3 conv layer F->F: acc[mt][nt] = sum over 9 taps x 256 channels (72 k-steps of 32).
+// Weight fragments come from a RING of RT*8 k-steps held in VGPRs that never drains: the packed tower weights of
+// all layers are one contiguous stream in exactly consumption order, so a slot is refilled with the k-step one ring
+// ahead right after its MFMAs issue — also across layer boundaries, where the epilogue + barrier then overlap the
+// next layer's weight latency.  `wcur` = this lane's pointer to the fragment of the current k-step.  A fragments
+// are double-buffered one k-step ahead so their LDS latency hides under the current MFMAs; every k-step is one
+// scheduling region (sched_barrier) so the refill stays right behind the MFMAs that free the slot.
+// PAR = parity of the layer's first tap in the global tap sequence (9 taps per layer: it alternates per layer).
+template <int MT, int RT, int PAR>
+__device__ __forceinline__ void conv_tower_layer(const uint8_t* IN, const s16x8* __restrict__& wcur, s16x8 (&bq)[RT * 8][2],
+                                                 f32x4 (&acc)[MT][2], const int (&rinfo)[MT], int g16, int zero_row)
 {
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) { acc[mt][0] = f32x4{0, 0, 0, 0}; acc[mt][1] = f32x4{0, 0, 0, 0}; }
-    s16x8 bq[2][4][2];
-    constexpr size_t KSTRIDE = FRAGS_PER_KSTEP * 64;  // s16x8 units between consecutive k-steps
+    int aoff[MT];
+    s16x8 a[2][MT];
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) { bq[0][kk][0] = wp[kk * KSTRIDE]; bq[0][kk][1] = wp[kk * KSTRIDE + 64]; }
-    for (int tap = 0; tap < 9; tap++) {
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        int aoff[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) aoff[mt] = tap_row(rinfo[mt], dy, dx, zero_row) * ROWB + g16;
-        const s16x8* wt = wp + (size_t)tap * KS_PER_TAP * KSTRIDE;
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            // prefetch the next chunk of 4 k-steps (second half of this tap, or first half of the next tap)
-            if (half == 0 || tap < 8) {
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++) {
-                    const s16x8* src = wt + (size_t)((half + 1) * 4 + kk) * KSTRIDE;
-                    bq[half ^ 1][kk][0] = src[0];
-                    bq[half ^ 1][kk][1] = src[64];
-                }
-            }
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                const int ks = half * 4 + kk;
-                s16x8 a[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++) a[mt] = *reinterpret_cast<const s16x8*>(IN + aoff[mt] + ks * 64);
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++) {
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[mt]),
-                                                                         __builtin_bit_cast(bf16x8, bq[half][kk][0]), acc[mt][0], 0, 0, 0);
-                    acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[mt]),
-                                                                         __builtin_bit_cast(bf16x8, bq[half][kk][1]), acc[mt][1], 0, 0, 0);
-                }
-            }
+    for (int mt = 0; mt < MT; mt++) {
+        aoff[mt] = tap_row(rinfo[mt], -1, -1, zero_row) * ROWB + g16;
+        a[0][mt] = *reinterpret_cast<const s16x8*>(IN + aoff[mt]);
+    }
+    if constexpr (RT == 1) {
+        for (int tap = 0; tap < 9; tap++) conv_tap<MT, 1, 0>(IN, tap, wcur, bq, acc, a, aoff, rinfo, g16, zero_row);
+    } else {
+        constexpr int S0 = PAR ? 8 : 0, S1 = PAR ? 0 : 8;
+        for (int tap = 0; tap < 8; tap += 2) {
+            conv_tap<MT, 2, S0>(IN, tap, wcur, bq, acc, a, aoff, rinfo, g16, zero_row);
+            conv_tap<MT, 2, S1>(IN, tap + 1, wcur, bq, acc, a, aoff, rinfo, g16, zero_row);
         }
+        conv_tap<MT, 2, S0>(IN, 8, wcur, bq, acc, a, aoff, rinfo, g16, zero_row);
     }
 }
 
@@ -196,6 +227,13 @@ __global__ __launch_bounds__(512, 2) void k_tower_bf16(const uint8_t* __restrict
     }
     f32x4 acc[MT][2];
 
+    // ---- start the weight ring: the first RING k-steps of layer 0 fly while the stem runs
+    const s16x8* __restrict__ wcur = reinterpret_cast<const s16x8*>(tower_wp) + (size_t)(wave * 2) * 64 + lane;
+    constexpr int RT = RingTaps<NB>::value;
+    s16x8 bq[RT * 8][2];
+#pragma unroll
+    for (int ks = 0; ks < RT * 8; ks++) { bq[ks][0] = wcur[ks * KSTRIDE]; bq[ks][1] = wcur[ks * KSTRIDE + 64]; }
+
     // ---- stem: 3x3 conv 13 -> 256, two taps per 32-deep k-step (tap slot = 2*ks + (g >> 1), channels (g & 1)*8 ..)
     {
 #pragma unroll
@@ -215,18 +253,26 @@ __global__ __launch_bounds__(512, 2) void k_tower_bf16(const uint8_t* __restrict
             }
         }
         // conv_bn over the board row + ReLU -> bufX   (C/D layout: col = lane & 15, row = (lane >> 4)*4 + j)
+        float rsc[MT][4], rsh[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r = mt * 16 + g * 4 + j;
+                const int y = r < ROWS ? (r % 42) / 6 : 0;
+                rsc[mt][j] = fold[y];
+                rsh[mt][j] = fold[7 + y];
+            }
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int r = mt * 16 + g * 4 + j;
                 if (r < ROWS) {
-                    const int y = (r % 42) / 6;
-                    const float sc = fold[y], sh = fold[7 + y];
 #pragma unroll
                     for (int nt = 0; nt < 2; nt++) {
                         const int co = wave * 32 + nt * 16 + m;
-                        float v = fmaf(acc[mt][nt][j], sc, sh);
+                        float v = fmaf(acc[mt][nt][j], rsc[mt][j], rsh[mt][j]);
                         reinterpret_cast<uint16_t*>(bufX + r * ROWB)[co] = bf_rne(v > 0.0f ? v : 0.0f);
                     }
                 }
@@ -236,16 +282,7 @@ __global__ __launch_bounds__(512, 2) void k_tower_bf16(const uint8_t* __restrict
 
     // ---- residual tower: 2 conv layers per block, activations resident in LDS
     const int g16 = g * 16;
-    for (int layer = 0; layer < 2 * blocks; layer++) {
-        const bool second = layer & 1;
-        const uint8_t* IN = second ? bufT : bufX;
-        uint8_t* OUT = second ? bufX : bufT;
-        const s16x8* wp = reinterpret_cast<const s16x8*>(tower_wp + (size_t)layer * TOWER_LAYER_HALFS) + (size_t)(wave * 2) * 64 + lane;
-        conv_tower_layer<MT>(IN, wp, acc, rinfo, g16, ROWS);
-        const float* fs = fold + 14 + (size_t)layer * 2 * NF;
-        float sc[2], sh[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++) { sc[nt] = fs[wave * 32 + nt * 16 + m]; sh[nt] = fs[NF + wave * 32 + nt * 16 + m]; }
+    auto epilogue = [&](int layer, bool second, uint8_t* OUT, const float (&sc)[2], const float (&sh)[2]) {
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -262,6 +299,21 @@ __global__ __launch_bounds__(512, 2) void k_tower_bf16(const uint8_t* __restrict
                     }
                 }
             }
+    };
+    for (int blk = 0; blk < blocks; blk++) {
+        // each layer's folded BN is requested before its taps so the epilogue never waits behind the weight ring
+        float sc[2], sh[2];
+        const float* fs = fold + 14 + (size_t)(2 * blk) * 2 * NF;
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) { sc[nt] = fs[wave * 32 + nt * 16 + m]; sh[nt] = fs[NF + wave * 32 + nt * 16 + m]; }
+        conv_tower_layer<MT, RT, 0>(bufX, wcur, bq, acc, rinfo, g16, ROWS);
+        epilogue(2 * blk, false, bufT, sc, sh);
+        __syncthreads();
+        fs += 2 * NF;
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) { sc[nt] = fs[wave * 32 + nt * 16 + m]; sh[nt] = fs[NF + wave * 32 + nt * 16 + m]; }
+        conv_tower_layer<MT, RT, 1>(bufT, wcur, bq, acc, rinfo, g16, ROWS);
+        epilogue(2 * blk + 1, true, bufX, sc, sh);
         __syncthreads();
     }
 
@@ -291,7 +343,8 @@ int net_bf16_alloc(azr_engine* h)
     h->net.bf16ctx = x;
     const int B = h->net.blocks;
     HIPCHK(h, hipMalloc((void**)&x->stem_wp, STEM_HALFS * 2));
-    HIPCHK(h, hipMalloc((void**)&x->tower_wp, (size_t)2 * B * TOWER_LAYER_HALFS * 2));
+    HIPCHK(h, hipMalloc((void**)&x->tower_wp, ((size_t)2 * B * TOWER_LAYER_HALFS + MAX_RING * KSTRIDE * 8) * 2));  // + ring run-off
+    HIPCHK(h, hipMemsetAsync(x->tower_wp, 0, ((size_t)2 * B * TOWER_LAYER_HALFS + MAX_RING * KSTRIDE * 8) * 2, h->stream));
     HIPCHK(h, hipMalloc((void**)&x->act, (size_t)h->d.G * NPOS * NF * 2));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<1>::LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<2>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<2>::LDS_BYTES));
@@ -353,6 +406,7 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
     Bf16Net* x = bn(h);
     const float* fold = net_fold(h);
     const int B = h->net.blocks;
+    if (h->pe_tower0) hipEventRecord(h->pe_tower0, h->stream);
     // boards per workgroup: fill the 256 CUs first, then grow the M tile
     if (n <= 256) {
         hipLaunchKernelGGL(k_tower_bf16<1>, dim3(n), dim3(512), Geo<1>::LDS_BYTES, h->stream, d_in88, in_stride, n,
@@ -364,6 +418,7 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
         hipLaunchKernelGGL(k_tower_bf16<3>, dim3((n + 2) / 3), dim3(512), Geo<3>::LDS_BYTES, h->stream, d_in88, in_stride, n,
                            x->stem_wp, x->tower_wp, fold, B, x->act);
     }
+    if (h->pe_tower1) hipEventRecord(h->pe_tower1, h->stream);
     launch_heads_bf16(h->stream, n, x->act, net_head_params(h), d_pi, d_v);
     HIPCHK(h, hipGetLastError());
     return AZR_OK;
