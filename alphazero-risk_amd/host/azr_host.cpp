@@ -1,0 +1,451 @@
+// azr_host.cpp — implementation of the reference-shaped host classes over the C-ABI (see azr_host.hpp).
+#include "azr_host.hpp"
+
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <iostream>
+#include <map>
+#include <sstream>
+
+namespace azrhost {
+
+Settings SETTINGS;
+
+// ---- Settings ---------------------------------------------------------------------------------------------------
+namespace {
+struct Opt { const char* name; const char* desc; std::string def; bool is_bool; };
+
+bool parse_bool(const std::string& v) { return !(v == "0" || v == "false" || v == "False" || v == "no"); }
+
+void mkdirs(const std::string& path)
+{
+    std::string cur;
+    for (size_t i = 0; i < path.size(); i++) {
+        cur += path[i];
+        if (path[i] == '/' || i + 1 == path.size()) mkdir(cur.c_str(), 0777);
+    }
+}
+}  // namespace
+
+void Settings::init(int argc, char* argv[])
+{
+    // name, description (as the reference's help text), default — settings.h:91-137
+    std::vector<Opt> opts = {
+        {"m", "Mode [train/play]", MODE, false},
+        {"g", "Default graph file path", DEFAULT_GRAPH_DEF_PB, false},
+        {"c", "Checkpoint file path", DEFAULT_LATEST_CHECKPOINT, false},
+        {"p1", "Player 1 [az/sp]", PLAYER_1, false},
+        {"g1", "Graph file path for player 1", GRAPH_DEF_PB_1, false},
+        {"c1", "Checkpoint file path for player 1", CHECKPOINT_1, false},
+        {"p2", "Player 2 [az/sp]", PLAYER_2, false},
+        {"g2", "Graph file path for player 2", GRAPH_DEF_PB_2, false},
+        {"c2", "Checkpoint file path for player 2", CHECKPOINT_2, false},
+        {"gpus", "Number of gpu units", std::to_string(NUMBER_OF_GPUS), false},
+        {"gpu-games", "Number of concurent games per gpu", std::to_string(NUMBER_OF_CONCURENT_GAMES_PER_GPU), false},
+        {"t", "Number of threads", std::to_string(THREADS_PER_MCTS), false},
+        {"apbs", "Set number of games per gpu to get avg. prediction batch size", std::to_string(AVG_PRED_BATCH_SIZE), false},
+        {"lnt", "Log nn training", std::to_string(LOG_NN_TRAINING), true},
+        {"ls", "Log state", std::to_string(LOG_STATE), true},
+        {"dgss", "Number of data games for trin-data script vs script", std::to_string(DATA_GAMES_SS), false},
+        {"dgsr", "Number of data games for trin-data script vs random", std::to_string(DATA_GAMES_SR), false},
+        {"dtl", "Number of train loops for data games", std::to_string(DATA_TRAIN_LOOPS), false},
+        {"allow-yield", "Allow yield when enemy ownes 3/4 of lands", std::to_string(ALLOW_YIELD), true},
+        {"limit-reinforcement", "Limit reinforcement moves", std::to_string(LIMIT_REINFORCEMENT_MOVES), true},
+        {"limit-attack", "Limit attack moves", std::to_string(LIMIT_ATTACK_MOVES), true},
+        {"mirror-games", "Play games in pair with mirrored initial position", std::to_string(MIRROR_GAMES), true},
+        {"ti", "Number of train iterations", std::to_string(TRAIN_ITERATIONS), false},
+        {"tg", "Games played per train iteration", std::to_string(TRAIN_ITERATION_GAMES), false},
+        {"mcts", "Number of MCTS simulations", std::to_string(MCTS_SIMULATIONS), false},
+        {"hp", "Exploration factor", std::to_string(HP_EXPLORATION), false},
+        {"dnv", "Dirchlet noise value", std::to_string(DIR_NOISE_VALUE), false},
+        {"dne", "Dirchlet noise epsi", std::to_string(DIR_NOISE_EPSI), false},
+        {"temp", "Temperature trehsold", std::to_string(TEMPERATURE_TRESHOLD), false},
+        {"e", "Number of epochs per train iteration", std::to_string(EPOCHS), false},
+        {"bs", "Batch size", std::to_string(BATCH_SIZE), false},
+        {"cg", "Number of games for comparison", std::to_string(COMPARE_GAMES), false},
+        {"ct", "Treshold for accepted improvement", std::to_string(COMPARE_TRESHOLD), false},
+        {"s", "Number of stored samples", std::to_string(SAMPLES_STORAGE_MIN), false},
+        {"blocks", "[this build] residual blocks of the net (reference: compile-time BLOCKS)", std::to_string(BLOCKS), false},
+        {"dtype", "[this build] net contraction dtype bf16|f32", NET_DTYPE, false},
+        {"seed", "[this build] base seed of the per-game RNG streams", std::to_string(BASE_SEED), false},
+        {"help", "Display help", "0", true},
+    };
+    std::map<std::string, std::string> val;
+    std::map<std::string, bool> given;
+    auto find = [&](const std::string& n) -> const Opt* {
+        for (auto& o : opts) if (n == o.name) return &o;
+        return nullptr;
+    };
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        if (a == "-h") a = "--help";
+        std::string name, value;
+        bool has_value = false;
+        if (a.rfind("--", 0) == 0) {
+            size_t eq = a.find('=');
+            name = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+            if (eq != std::string::npos) { value = a.substr(eq + 1); has_value = true; }
+        } else if (a.size() >= 2 && a[0] == '-') {
+            name = a.substr(1, 1);  // cxxopts: one-letter names are short options (-m train, -mtrain, -t 1)
+            if (a.size() > 2) { value = a.substr(a[2] == '=' ? 3 : 2); has_value = true; }
+        } else {
+            fprintf(stderr, "unexpected argument '%s'\n", a.c_str());
+            exit(2);
+        }
+        const Opt* o = find(name);
+        if (!o) { fprintf(stderr, "Option '%s' does not exist\n", name.c_str()); exit(2); }
+        if (!has_value) {
+            if (o->is_bool && (i + 1 >= argc || argv[i + 1][0] == '-')) value = "1";
+            else if (i + 1 < argc) value = argv[++i];
+            else { fprintf(stderr, "Option '%s' is missing an argument\n", name.c_str()); exit(2); }
+        }
+        val[name] = value;
+        given[name] = true;
+    }
+    auto get = [&](const char* n) { return given.count(n) ? val[n] : find(n)->def; };
+    if (given.count("help")) {
+        printf("AlphaZero implementation for game Risk (MI355X-native hot path)\nUsage:\n  AlphaZero-Risk [OPTION...]\n\n");
+        for (auto& o : opts) printf("  %s%-22s %s (default: %s)\n", strlen(o.name) == 1 ? " -" : "--", o.name, o.desc, o.def.c_str());
+        exit(0);
+    }
+    MODE = get("m");
+    if (MODE == "learn") MODE = "train";  // BASELINE.json calls the reference's `train` mode `learn`
+    DEFAULT_GRAPH_DEF_PB = get("g");
+    DEFAULT_LATEST_CHECKPOINT = get("c");
+    PLAYER_1 = get("p1"); GRAPH_DEF_PB_1 = get("g1"); CHECKPOINT_1 = get("c1");
+    PLAYER_2 = get("p2"); GRAPH_DEF_PB_2 = get("g2"); CHECKPOINT_2 = get("c2");
+    THREADS_PER_MCTS = atoi(get("t").c_str());
+    NUMBER_OF_GPUS = atoi(get("gpus").c_str());
+    if (given.count("gpu-games")) NUMBER_OF_CONCURENT_GAMES_PER_GPU = atoi(get("gpu-games").c_str());
+    else NUMBER_OF_CONCURENT_GAMES_PER_GPU = AVG_PRED_BATCH_SIZE / (THREADS_PER_MCTS > 0 ? THREADS_PER_MCTS : 1) * 2;
+    DATA_GAMES_SS = atoi(get("dgss").c_str());
+    DATA_GAMES_SR = atoi(get("dgsr").c_str());
+    DATA_TRAIN_LOOPS = atoi(get("dtl").c_str());
+    LOG_STATE = parse_bool(get("ls"));
+    ALLOW_YIELD = parse_bool(get("allow-yield"));
+    LIMIT_REINFORCEMENT_MOVES = parse_bool(get("limit-reinforcement"));
+    LIMIT_ATTACK_MOVES = parse_bool(get("limit-attack"));
+    MIRROR_GAMES = parse_bool(get("mirror-games"));
+    TRAIN_ITERATIONS = atol(get("ti").c_str());
+    TRAIN_ITERATION_GAMES = atoi(get("tg").c_str());
+    MCTS_SIMULATIONS = atoi(get("mcts").c_str());
+    HP_EXPLORATION = (float)atof(get("hp").c_str());
+    DIR_NOISE_VALUE = (float)atof(get("dnv").c_str());
+    DIR_NOISE_EPSI = (float)atof(get("dne").c_str());
+    TEMPERATURE_TRESHOLD = atoi(get("temp").c_str());
+    EPOCHS = atoi(get("e").c_str());
+    BATCH_SIZE = atoi(get("bs").c_str());
+    COMPARE_GAMES = atoi(get("cg").c_str());
+    COMPARE_TRESHOLD = (float)atof(get("ct").c_str());
+    SAMPLES_STORAGE_MIN = atoi(get("s").c_str());
+    BLOCKS = atoi(get("blocks").c_str());
+    NET_DTYPE = get("dtype");
+    BASE_SEED = (uint32_t)strtoul(get("seed").c_str(), nullptr, 10);
+    // `--lnt` and `--apbs` are parsed and never applied in the reference either
+    mkdirs("log");
+    std::ofstream out("log/settings.txt", std::ofstream::out);
+    for (auto& o : opts) out << o.name << "(" << o.desc << ")=" << (given.count(o.name) ? val[o.name] : o.def) << std::endl;
+}
+
+void Settings::toEngine(azr_settings& s, int device) const
+{
+    azr_default_settings(&s);
+    s.device = device;
+    s.games = NUMBER_OF_CONCURENT_GAMES_PER_GPU;
+    s.blocks = BLOCKS;
+    s.net_dtype = NET_DTYPE == "f32" ? AZR_NET_F32 : AZR_NET_BF16;
+    s.mcts_simulations = MCTS_SIMULATIONS;
+    s.allow_yield = ALLOW_YIELD;
+    s.limit_reinforcement = LIMIT_REINFORCEMENT_MOVES;
+    s.limit_attack = LIMIT_ATTACK_MOVES;
+    s.max_game_rounds = MAX_GAME_ROUNDS;
+    s.min_unit_move = MIN_UNIT_MOVE;
+    s.temperature_threshold = TEMPERATURE_TRESHOLD;
+    s.hp_exploration = HP_EXPLORATION;
+    s.dir_noise_value = DIR_NOISE_VALUE;
+    s.dir_noise_epsi = DIR_NOISE_EPSI;
+}
+
+std::string Settings::describe() const
+{
+    std::ostringstream o;
+    o << "GPUs: " << NUMBER_OF_GPUS << ", Games per GPU " << NUMBER_OF_CONCURENT_GAMES_PER_GPU << ", MCTS threads: "
+      << THREADS_PER_MCTS << ", MCTS simulations " << MCTS_SIMULATIONS;
+    return o.str();
+}
+
+// ---- samples ---------------------------------------------------------------------------------------------------------
+void NNTrainDataStorage::appendPacked(const uint8_t* rec, size_t n)
+{
+    data.reserve(data.size() + n);
+    for (size_t i = 0; i < n; i++, rec += AZR_RECORD_BYTES) {
+        NNTrainData d;
+        d.playerIndex = (int8_t)rec[0];
+        memcpy(d.in.bytes, rec + 1, AZR_INPUT_BYTES);
+        memcpy(&d.out.value, rec + 89, 4);
+        d.out.policy.resize(AZR_MOVES);
+        memcpy(d.out.policy.data(), rec + 93, AZR_MOVES * 4);
+        data.push_back(std::move(d));
+    }
+}
+
+void NNTrainDataStorage::trimOldExamples()
+{
+    if (data.size() > (size_t)SETTINGS.SAMPLES_STORAGE_MAX) {
+        size_t excess = data.size() - SETTINGS.SAMPLES_STORAGE_MAX;
+        data.erase(data.begin(), data.begin() + excess);
+        printf("[MAX] Erased %d oldeset examples\n", int(excess));
+    } else if (data.size() > (size_t)SETTINGS.SAMPLES_STORAGE_MIN && oldGameIndex > 0) {
+        size_t excess = std::min(oldGameIndex, data.size() - SETTINGS.SAMPLES_STORAGE_MIN);
+        oldGameIndex -= excess;
+        data.erase(data.begin(), data.begin() + excess);
+        printf("[MIN] Erased %d oldeset examples\n", int(excess));
+    }
+}
+
+void NNTrainDataStorage::saveTrainingSamples(const std::string& path) const
+{
+    if (data.empty()) { printf("No training samples\n"); return; }
+    size_t slash = path.find_last_of('/');
+    if (slash != std::string::npos) mkdirs(path.substr(0, slash));
+    std::ofstream out(path, std::ios::out | std::ios::binary);
+    uint64_t size = data.size();
+    out.write((const char*)&size, 8);
+    for (auto& d : data) {
+        out.write((const char*)&d.playerIndex, 1);
+        out.write((const char*)d.in.bytes, AZR_INPUT_BYTES);
+        out.write((const char*)&d.out.value, 4);
+        out.write((const char*)d.out.policy.data(), 4 * AZR_MOVES);
+    }
+    printf("Training samples saved %d\n", int(data.size()));
+}
+
+void NNTrainDataStorage::loadTrainingSamples(const std::string& path)
+{
+    std::ifstream in(path, std::ios::in | std::ios::binary | std::ios::ate);
+    if (!in) { printf("File does note exist: %s\n", path.c_str()); return; }
+    const uint64_t bytes = (uint64_t)in.tellg();
+    in.seekg(0);
+    // the reference's writer emits an 8-byte count, its reader consumes 4 bytes: accept whichever fits the file size
+    uint64_t n8 = 0;
+    in.read((char*)&n8, 8);
+    size_t header = 8;
+    uint64_t n = n8;
+    if (bytes != 8 + n8 * AZR_RECORD_BYTES) {
+        uint32_t n4 = (uint32_t)n8;
+        if (bytes == 4 + (uint64_t)n4 * AZR_RECORD_BYTES) { n = n4; header = 4; }
+        else { printf("Unrecognised sample file: %s\n", path.c_str()); return; }
+    }
+    in.seekg(header);
+    std::vector<uint8_t> buf(n * AZR_RECORD_BYTES);
+    in.read((char*)buf.data(), buf.size());
+    appendPacked(buf.data(), n);
+}
+
+// ---- engine / NN service ------------------------------------------------------------------------------------------
+Engine::Engine(const Settings& s, int device, int g) : games(g)
+{
+    azr_settings es;
+    s.toEngine(es, device);
+    es.games = g;
+    int rc = azr_engine_create(&es, &h);
+    if (rc) {
+        std::string msg = h ? azr_last_error(h) : "azr_engine_create failed";
+        if (h) azr_engine_destroy(h);
+        h = nullptr;
+        throw std::runtime_error("engine: " + msg);
+    }
+}
+Engine::~Engine() { if (h) azr_engine_destroy(h); }
+void Engine::check(int rc, const char* what) const
+{
+    if (rc == AZR_E_INVALID_ARGUMENT) throw std::invalid_argument(std::string(what) + ": " + azr_last_error(h));
+    if (rc == AZR_E_LOGIC) throw std::logic_error(std::string(what) + ": " + azr_last_error(h));
+    if (rc) throw std::runtime_error(std::string(what) + ": " + azr_last_error(h));
+}
+
+void AlphaZeroNNId::loadCheckpoint(const std::string& path)
+{
+    struct stat st;
+    if (stat(path.c_str(), &st) == 0) {
+        engine->check(azr_nn_load(engine->h, path.c_str()), "loadCheckpoint");
+        printf("Loaded checkpoint %s\n", path.c_str());
+    } else {  // alphazero_nn.cpp:197-202: no checkpoint => initialise and save one
+        printf("Checkpoint %s not found, initializing random weights\n", path.c_str());
+        engine->check(azr_nn_init_random(engine->h, 20260002ull), "init");
+        saveCheckpoint(path);
+    }
+}
+void AlphaZeroNNId::saveCheckpoint(const std::string& path)
+{
+    size_t slash = path.find_last_of('/');
+    if (slash != std::string::npos) mkdirs(path.substr(0, slash));
+    engine->check(azr_nn_save(engine->h, path.c_str()), "saveCheckpoint");
+}
+NNOutputData AlphaZeroNNId::predict(const NNInputData& in) { return predict(std::vector<NNInputData>{in})[0]; }
+std::vector<NNOutputData> AlphaZeroNNId::predict(const std::vector<NNInputData>& in)
+{
+    const int n = (int)in.size();
+    std::vector<uint8_t> x((size_t)n * AZR_INPUT_BYTES);
+    for (int i = 0; i < n; i++) memcpy(x.data() + (size_t)i * AZR_INPUT_BYTES, in[i].bytes, AZR_INPUT_BYTES);
+    std::vector<float> pi((size_t)n * AZR_MOVES), v(n);
+    engine->check(azr_nn_predict(engine->h, x.data(), n, pi.data(), v.data()), "predict");
+    std::vector<NNOutputData> out(n);
+    for (int i = 0; i < n; i++) {
+        out[i].policy.assign(pi.begin() + (size_t)i * AZR_MOVES, pi.begin() + (size_t)(i + 1) * AZR_MOVES);
+        out[i].value = v[i];
+    }
+    return out;
+}
+
+std::shared_ptr<AlphaZeroNNGroup> AlphaZeroCluster::initPlayerGroup(const std::string& name, const std::string& graphPath)
+{
+    for (auto& g : groups)
+        if (g->name == name) throw std::invalid_argument("Duplicated player group");  // alphazero_gpu_cluster.cpp:160-163
+    (void)graphPath;  // the TF graph-def is not used: the net is built into the HIP library (blocks = --blocks)
+    auto grp = std::make_shared<AlphaZeroNNGroup>();
+    grp->name = name;
+    for (int gpu = 0; gpu < gpus; gpu++) {
+        auto eng = std::make_shared<Engine>(SETTINGS, gpu, SETTINGS.NUMBER_OF_CONCURENT_GAMES_PER_GPU);
+        grp->neuralNetworkIds.push_back(std::make_shared<AlphaZeroNNId>(eng, gpu));
+    }
+    groups.push_back(grp);
+    return grp;
+}
+
+// ---- search ------------------------------------------------------------------------------------------------------------
+void AlphaZeroMCTS::clearNodes() { nn->engine->check(azr_mcts_clear(nn->engine->h), "clearNodes"); }
+void AlphaZeroMCTS::trimNodes() { nn->engine->check(azr_mcts_trim(nn->engine->h), "trimNodes"); }
+void AlphaZeroMCTS::simulate(const std::vector<State>& roots)
+{
+    Engine& e = *nn->engine;
+    if ((int)roots.size() != e.games) throw std::invalid_argument("simulate: one root per engine game expected");
+    std::vector<uint8_t> img((size_t)e.games * AZR_STATE_BYTES);
+    for (int g = 0; g < e.games; g++) memcpy(img.data() + (size_t)g * AZR_STATE_BYTES, roots[g].data, AZR_STATE_BYTES);
+    e.check(azr_engine_set_states(e.h, img.data()), "set_states");
+    e.check(azr_mcts_simulate(e.h), "simulate");
+}
+std::vector<std::vector<float>> AlphaZeroMCTS::calculateMoveProbability()
+{
+    Engine& e = *nn->engine;
+    std::vector<float> pi((size_t)e.games * AZR_MOVES);
+    e.check(azr_mcts_policy(e.h, pi.data()), "policy");
+    std::vector<std::vector<float>> out(e.games);
+    for (int g = 0; g < e.games; g++) out[g].assign(pi.begin() + (size_t)g * AZR_MOVES, pi.begin() + (size_t)(g + 1) * AZR_MOVES);
+    return out;
+}
+std::vector<uint8_t> AlphaZeroMCTS::pickHigestWeightedMove()
+{
+    std::vector<uint8_t> mv(nn->engine->games);
+    nn->engine->check(azr_mcts_pick(nn->engine->h, 0, mv.data()), "pick");
+    return mv;
+}
+std::vector<uint8_t> AlphaZeroMCTS::pickRandomWeightedMove()
+{
+    std::vector<uint8_t> mv(nn->engine->games);
+    nn->engine->check(azr_mcts_pick(nn->engine->h, 1, mv.data()), "pick");
+    return mv;
+}
+
+AlphaZeroPlayerGroup::AlphaZeroPlayerGroup(std::shared_ptr<AlphaZeroNNGroup> g) : nnGroup(g)
+{
+    for (size_t i = 0; i < g->size(); i++)
+        for (int k = 0; k < SETTINGS.NUMBER_OF_CONCURENT_GAMES_PER_GPU; k++) players.push_back(std::make_shared<Player>());
+}
+
+void AlphaZeroPlayerGroup::takeTurns(int gpu, std::vector<State>& states, int8_t playerIndexTurn)
+{
+    auto nn = nnGroup->getNN(gpu);
+    Engine& e = *nn->engine;
+    AlphaZeroMCTS mcts(nn);
+    const int G = e.games;
+    if ((int)states.size() != G) throw std::invalid_argument("takeTurns: one State per engine game expected");
+    std::vector<uint8_t> img((size_t)G * AZR_STATE_BYTES);
+    std::vector<int8_t> status(G);
+    mcts.trimNodes();  // AlphaZeroPlayer::takeTurn's own trim (alphazero_player.cpp:5)
+    for (;;) {
+        for (int g = 0; g < G; g++) memcpy(img.data() + (size_t)g * AZR_STATE_BYTES, states[g].data, AZR_STATE_BYTES);
+        e.check(azr_engine_set_states(e.h, img.data()), "set_states");
+        e.check(azr_engine_status(e.h, status.data()), "status");
+        bool any = false;
+        for (int g = 0; g < G; g++) any |= status[g] == -1 && states[g].getCurrentPlayerTurn() == playerIndexTurn;
+        if (!any) break;
+        e.check(azr_mcts_simulate(e.h), "simulate");
+        std::vector<uint8_t> mv = mcts.pickHigestWeightedMove();
+        for (int g = 0; g < G; g++)
+            if (!(status[g] == -1 && states[g].getCurrentPlayerTurn() == playerIndexTurn)) mv[g] = 255;
+        e.check(azr_engine_make_moves(e.h, mv.data(), nullptr), "makeMove");
+        e.check(azr_engine_get_states(e.h, img.data()), "get_states");
+        for (int g = 0; g < G; g++) memcpy(states[g].data, img.data() + (size_t)g * AZR_STATE_BYTES, AZR_STATE_BYTES);
+    }
+}
+
+// ---- trainer ------------------------------------------------------------------------------------------------------------
+SelfPlayReport AlphaZeroTrainer::generateTrainData(std::shared_ptr<AlphaZeroNNGroup> generate)
+{
+    const int P = (int)generate->size();
+    const uint64_t target = (uint64_t)SETTINGS.TRAIN_ITERATION_GAMES;
+    printf("Generating training data current sample count %d\n", int(trainStorage.data.size()));
+    std::vector<NNTrainDataStorage> storageGroup(P);
+    std::vector<SelfPlayReport> rep(P);
+    std::vector<std::thread> threads;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < P; i++) {
+        threads.emplace_back([&, i]() {  // one self-play thread per GPU (alphazero_trainer.cpp:48-57)
+            Engine& e = *generate->getNN(i)->engine;
+            const uint64_t share = target / P + ((uint64_t)i < target % P ? 1 : 0);
+            const uint32_t seed = SETTINGS.BASE_SEED + (uint32_t)i * (1u << 24) + (uint32_t)trainIteration * 65536u * (uint32_t)e.games;
+            e.check(azr_selfplay_start(e.h, seed), "selfplay_start");
+            azr_counters c{};
+            std::vector<uint8_t> buf;
+            while (c.games_finished < share) {
+                e.check(azr_selfplay_run(e.h, 4 * (SETTINGS.MCTS_SIMULATIONS + 2)), "selfplay_run");
+                e.check(azr_selfplay_counters(e.h, &c), "counters");
+                size_t n = 0;
+                buf.resize((size_t)e.games * 4096 * AZR_RECORD_BYTES / 8);
+                e.check(azr_samples_drain(e.h, buf.data(), buf.size() / AZR_RECORD_BYTES, &n), "drain");
+                storageGroup[i].appendPacked(buf.data(), n);
+                printf("\r[gpu %d] games %llu/%llu  decisions %llu  simulations %llu", i, (unsigned long long)c.games_finished,
+                       (unsigned long long)share, (unsigned long long)c.decisions, (unsigned long long)c.simulations);
+                fflush(stdout);
+            }
+            rep[i].games = c.games_finished; rep[i].decisions = c.decisions; rep[i].simulations = c.simulations;
+            rep[i].samples = storageGroup[i].data.size(); rep[i].errors = c.errors;
+        });
+    }
+    for (auto& t : threads) t.join();
+    SelfPlayReport tot;
+    tot.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const size_t before = trainStorage.data.size();
+    for (int i = 0; i < P; i++) {  // the "all-gather": concatenation in GPU order (alphazero_trainer.cpp:59-62)
+        trainStorage.extend(storageGroup[i]);
+        tot.games += rep[i].games; tot.decisions += rep[i].decisions; tot.simulations += rep[i].simulations;
+        tot.samples += rep[i].samples; tot.errors += rep[i].errors;
+    }
+    printf("\nGenerated %d new samples for total %d\n", int(trainStorage.data.size() - before), int(trainStorage.data.size()));
+    return tot;
+}
+
+void AlphaZeroTrainer::train(std::shared_ptr<AlphaZeroNNGroup> trainGroup, std::shared_ptr<AlphaZeroNNGroup> generateGroup)
+{
+    (void)trainGroup;
+    trainStorage.loadTrainingSamples(SETTINGS.DEFAULT_SAMPLES);
+    printf("Started training\n");
+    for (trainIteration = 0; trainIteration < SETTINGS.TRAIN_ITERATIONS; trainIteration++) {
+        printf("Train iteration %ld\n", trainIteration);
+        SelfPlayReport r = generateTrainData(generateGroup);
+        printf("Self-play: %llu games, %llu decisions, %llu simulations in %.2f s  =>  %.0f simulations/s, %.2f games/s\n",
+               (unsigned long long)r.games, (unsigned long long)r.decisions, (unsigned long long)r.simulations, r.seconds,
+               r.simulations / r.seconds, r.games / r.seconds);
+        trainStorage.trimOldExamples();
+        // trainGroup->train(...) + updateIfImprovement (alphazero_trainer.cpp:25-31) are SURVEY §8(f) "next" rows:
+        // the optimiser step and the arena are not built in this round, so the net stays at its checkpoint.
+        printf("[this round] train step / arena not built yet (SURVEY §8f-2): weights unchanged\n");
+    }
+    trainStorage.saveTrainingSamples(SETTINGS.DEFAULT_SAMPLES);
+}
+
+}  // namespace azrhost

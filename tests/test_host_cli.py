@@ -1,0 +1,72 @@
+"""The C++ host side (alphazero-risk_amd/host): reference-shaped Settings/CLI.  CPU part: flag parsing, defaults,
+log/settings.txt side effect, loud failure without a device.  GPU part: `-m learn` and `-m play` end to end."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from gpu_common import ROOT, have_gpu
+
+HOST = os.path.join(ROOT, "alphazero-risk_amd", "host")
+EXE = os.path.join(HOST, "AlphaZero_Risk_hip")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "alphazero-risk_amd", "csrc")])
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    return EXE
+
+
+def test_help_lists_every_reference_flag(exe):
+    out = subprocess.run([exe, "--help"], capture_output=True, text=True, check=True).stdout
+    for flag in ("-m", "-g", "-c", "--p1", "--g1", "--c1", "--p2", "--g2", "--c2", "--gpus", "--gpu-games", "-t", "--apbs",
+                 "--lnt", "--ls", "--dgss", "--dgsr", "--dtl", "--allow-yield", "--limit-reinforcement", "--limit-attack",
+                 "--mirror-games", "--ti", "--tg", "--mcts", "--hp", "--dnv", "--dne", "--temp", "-e", "--bs", "--cg",
+                 "--ct", "-s"):
+        assert flag.lstrip("-") in out, flag
+
+
+def test_settings_file_and_derived_gpu_games(exe, tmp_path):
+    if have_gpu():
+        pytest.skip("needs a box without a GPU (checks the loud failure)")
+    r = subprocess.run([exe, "-m", "learn", "--mcts=16", "-t", "4", "--ti=1"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "no ROCm-capable device" in r.stderr          # no CPU fallback
+    # --gpu-games default is derived: AVG_PRED_BATCH_SIZE / t * 2 (settings.h:163-171) = 32 / 4 * 2
+    assert "Games per GPU 16, MCTS threads: 4, MCTS simulations 16" in r.stdout
+    s = open(tmp_path / "log" / "settings.txt").read()
+    assert "m(Mode [train/play])=learn" in s and "mcts(Number of MCTS simulations)=16" in s
+    assert "cg(Number of games for comparison)=1000" in s
+
+
+def test_unknown_flag_is_an_error(exe, tmp_path):
+    r = subprocess.run([exe, "--nope=1"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 2 and "does not exist" in r.stderr
+
+
+@pytest.mark.gpu
+def test_learn_mode_generates_reference_format_samples(exe, tmp_path):
+    r = subprocess.run([exe, "-m", "learn", "--mcts=8", "--gpu-games=16", "--blocks=1", "--ti=1", "--tg=6", "--dtype=bf16"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "Generated" in r.stdout and "simulations/s" in r.stdout
+    raw = open(tmp_path / "data" / "training_samples.bin", "rb").read()
+    n = int(np.frombuffer(raw[:8], np.uint64)[0])
+    assert n > 0 and len(raw) == 8 + n * 265                                  # alphazero_nn_data.cpp:123-130
+    rec = np.frombuffer(raw[8:], np.uint8).reshape(n, 265)
+    pi = rec[:, 93:].copy().view(np.float32).reshape(n, 43)
+    z = rec[:, 89:93].copy().view(np.float32).reshape(n)
+    assert np.allclose(pi.sum(1), 1, atol=1e-4) and set(np.unique(z)) <= {-1.0, 0.0, 1.0}
+    assert os.path.exists(tmp_path / "checkpoints" / "latest-checkpoint.bin")  # missing checkpoint => init + save
+
+
+@pytest.mark.gpu
+def test_play_mode_az_vs_az(exe, tmp_path):
+    r = subprocess.run([exe, "-m", "play", "--p1=az", "--p2=az", "--mcts=4", "--gpu-games=8", "--blocks=1", "--cg=8"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    tail = r.stdout.strip().split("\n")[-4:]
+    assert tail[0] == "Games: 8"
+    d, p1, p2 = (int(t.split(":")[1]) for t in tail[1:])
+    assert d + p1 + p2 == 8
