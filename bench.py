@@ -42,7 +42,7 @@ def cpu_baseline(blocks, sims, seconds_budget=25.0):
 
     orc = T.oracle()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(cores, 64))
+    threads = max(1, min(cores, 64))  # "cores" reported = threads actually used
     flat = T.make_net_flat(blocks)
     net = T.OrcNet(blocks, flat.ctypes.data_as(T.f32p))
     cfg = T.default_settings(mcts_simulations=sims)
@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-games", action="store_true",
+                    help="skip the untimed tail that plays on until G games have finished (self-play games/s)")
     a = ap.parse_args()
 
     import torch
@@ -102,6 +104,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_start = time.perf_counter()
     eng.selfplay_run(a.warmup)
     eng.drain(1)  # reset the record ring
     c0 = eng.counters()
@@ -127,6 +130,23 @@ def main():
     dt = float(tmax.item())
     sims, evals, levels, decisions, games, samples, errors, dropped = [int(x) for x in tot.tolist()]
 
+    # untimed tail (N = 1 only): keep playing until G games have finished to measure whole self-play games/s
+    games_rate = None
+    if world == 1 and not a.no_full_games:
+        t_tail = time.perf_counter()
+        while time.perf_counter() - t_tail < 120.0:
+            eng.selfplay_run(2000)
+            eng.drain(1)
+            ct = eng.counters()
+            if ct["games_finished"] >= a.games:
+                break
+        ct = eng.counters()
+        el = time.perf_counter() - t_start
+        if ct["games_finished"] > 0:
+            games_rate = {"games_per_s": ct["games_finished"] / el, "games": ct["games_finished"],
+                          "decisions_per_finished_game": ct["samples"] / ct["games_finished"],
+                          "window_s": el, "simulations_per_s_over_window": ct["simulations"] / el}
+
     if rank == 0:
         fps = flop_per_sim(a.blocks)
         net_s = prof["net_ms"] * 1e-3
@@ -140,7 +160,8 @@ def main():
                                    f"{a.blocks}-block 256-filter random-init net (BASELINE configs[1])",
                        "games_per_gpu": a.games, "sims_per_move": a.sims, "blocks": a.blocks,
                        "parallelism": f"games sharded x{world}, no data-path collective; 1 all_gather of records"},
-            "self_play_games_per_s": games / dt, "decisions_per_s": decisions / dt,
+            "self_play_games_per_s": games_rate["games_per_s"] if games_rate else games / dt,
+            "self_play_games_window": games_rate, "decisions_per_s": decisions / dt,
             "net_evals_per_s": evals / dt, "mean_depth": levels / max(1, sims),
             "games_finished": games, "records_gathered": int(allrecs.shape[0]), "errors": errors,
             "nodes_dropped": dropped,
@@ -148,7 +169,11 @@ def main():
                          if a.dtype == "bf16" else "fp32 conv chain", "achieved": achieved / 1e12,
                          "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
                          "flop_per_launch": a.games * fps, "avg_launch_ms": prof["net_ms"],
-                         "tree_step_avg_ms": prof["tree_ms"], "timed_launches": prof["launches"], "traffic": None},
+                         "tree_step_avg_ms": prof["tree_ms"], "timed_launches": prof["launches"],
+                         # HBM-side bytes per launch from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction),
+                         # profiles/r01_pmc_fetch_write_g256_s100_b20.txt — measured for exactly this configuration
+                         "traffic": (2 * 186129.7 + 5376.0) * 1024
+                         if (a.games, a.blocks, a.dtype) == (256, 20, "bf16") else None},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.blocks, a.sims)
