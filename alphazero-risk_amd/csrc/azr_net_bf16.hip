@@ -15,6 +15,7 @@
 //     the LDS image being replaced), ReLU, round-to-nearest-even bf16, written straight back into LDS.
 //   * conv_bn of the stem normalises over the board ROW (build_graph.py:68 axis=1): per-row scale/shift.
 // One barrier per layer.  The heads (1x1 convs + dense layers, 47 k MAC/board) run as a second small kernel.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -103,22 +104,26 @@ struct Geo {
     static constexpr int LDS_BYTES = 2 * BUF + NB * 96;
 };
 
-// One 3x3 conv layer F->F: acc[mt][nt] = sum over 9 taps x 256 channels (72 k-steps of 32).
-// Weight fragments come from a RING of RING k-steps held in VGPRs that never drains: the packed tower weights of
-// all layers are one contiguous stream in exactly consumption order, so slot (k-step % RING) is refilled with the
-// k-step RING ahead right after its MFMAs issue — also across layer boundaries, where the epilogue + barrier then
-// overlap the next layer's weight latency.  `wcur` = this lane's pointer to the fragment of the current k-step.
 constexpr size_t KSTRIDE = FRAGS_PER_KSTEP * 64;  // s16x8 units between consecutive k-steps
 constexpr int MAX_RING = 16;
 
-// ring depth in taps (8 k-steps each): the 1-board tile has VGPRs to spare and needs the most bytes in flight
-template <int NB> struct RingTaps { static constexpr int value = NB == 1 ? 2 : 1; };
+// ---------------------------------------------------------------------------------------------------------------
+// Wave tiling: the 16 column tiles (16 channels each) of N = 256 are split over WAVES = 16 / NT waves, NT tiles per
+// wave.  NT = 2 -> 8 waves (2 per SIMD, <= 256 VGPRs);  NT = 4 -> 4 waves (ONE per SIMD, up to 512 VGPRs): every A
+// fragment read from LDS then feeds 4 MFMAs instead of 2, halving the LDS traffic that co-limits the 8-wave shape.
+// The packed weight stream is identical for both (fragment index = column tile).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr size_t KBYTES = KSTRIDE * 16;  // bytes per k-step of packed weights (all 16 column tiles)
 
-// one tap = 8 k-steps against ring slots SB .. SB+7
-template <int MT, int RT, int SB>
-__device__ __forceinline__ void conv_tap(const uint8_t* IN, int tap, const s16x8* __restrict__& wcur, s16x8 (&bq)[RT * 8][2],
-                                         f32x4 (&acc)[MT][2], s16x8 (&a)[2][MT], int (&aoff)[MT], const int (&rinfo)[MT],
-                                         int g16, int zero_row)
+// ring depth in taps (8 k-steps each)
+template <int NB, int NT> struct RingTaps { static constexpr int value = (NB == 1) ? 2 : 1; };
+
+// one tap = 8 k-steps against ring slots SB .. SB+7.  `wb` is the wave-UNIFORM byte pointer to the current
+// k-step's 16-KiB fragment block (advanced with scalar adds); `loff` is this lane's byte offset inside a block.
+template <int MT, int NT, int RT, int SB>
+__device__ __forceinline__ void conv_tap(const uint8_t* IN, int tap, const char* __restrict__& wb, uint32_t loff,
+                                         s16x8 (&bq)[RT * 8][NT], f32x4 (&acc)[MT][NT], s16x8 (&a)[2][MT], int (&aoff)[MT],
+                                         const int (&rinfo)[MT], int g16, int zero_row)
 {
     const int ntap = tap < 8 ? tap + 1 : 8;
     const int ndy = ntap / 3 - 1, ndx = ntap % 3 - 1;
@@ -128,20 +133,23 @@ __device__ __forceinline__ void conv_tap(const uint8_t* IN, int tap, const s16x8
 #pragma unroll
     for (int ks = 0; ks < KS_PER_TAP; ks++) {
         const int cur = ks & 1, nxt = cur ^ 1;
+        // (1) LDS reads of the NEXT k-step's A fragments go out first ...
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
             a[nxt][mt] = ks < KS_PER_TAP - 1 ? *reinterpret_cast<const s16x8*>(IN + aoff[mt] + (ks + 1) * 64)
                                              : *reinterpret_cast<const s16x8*>(IN + noff[mt]);
+        __builtin_amdgcn_sched_barrier(0);
+        // (2) ... and fly under this k-step's MFMAs; then the freed ring slot is refilled one ring ahead
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-            acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[cur][mt]),
-                                                                 __builtin_bit_cast(bf16x8, bq[SB + ks][0]), acc[mt][0], 0, 0, 0);
-            acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[cur][mt]),
-                                                                 __builtin_bit_cast(bf16x8, bq[SB + ks][1]), acc[mt][1], 0, 0, 0);
-        }
-        bq[SB + ks][0] = wcur[RT * 8 * KSTRIDE];
-        bq[SB + ks][1] = wcur[RT * 8 * KSTRIDE + 64];
-        wcur += KSTRIDE;
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[cur][mt]),
+                                                                      __builtin_bit_cast(bf16x8, bq[SB + ks][nt]), acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+            bq[SB + ks][nt] = *reinterpret_cast<const s16x8*>(wb + RT * 8 * KBYTES + loff + nt * 1024);
+        wb += KBYTES;
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -152,16 +160,18 @@ __device__ __forceinline__ void conv_tap(const uint8_t* IN, int tap, const s16x8
 // Weight fragments come from a RING of RT*8 k-steps held in VGPRs that never drains: the packed tower weights of
 // all layers are one contiguous stream in exactly consumption order, so a slot is refilled with the k-step one ring
 // ahead right after its MFMAs issue — also across layer boundaries, where the epilogue + barrier then overlap the
-// next layer's weight latency.  `wcur` = this lane's pointer to the fragment of the current k-step.  A fragments
-// are double-buffered one k-step ahead so their LDS latency hides under the current MFMAs; every k-step is one
-// scheduling region (sched_barrier) so the refill stays right behind the MFMAs that free the slot.
+// next layer's weight latency.  A fragments are double-buffered one k-step ahead so their LDS latency hides under
+// the current MFMAs; scheduling regions (sched_barrier) keep that order.
 // PAR = parity of the layer's first tap in the global tap sequence (9 taps per layer: it alternates per layer).
-template <int MT, int RT, int PAR>
-__device__ __forceinline__ void conv_tower_layer(const uint8_t* IN, const s16x8* __restrict__& wcur, s16x8 (&bq)[RT * 8][2],
-                                                 f32x4 (&acc)[MT][2], const int (&rinfo)[MT], int g16, int zero_row)
+template <int MT, int NT, int RT, int PAR>
+__device__ __forceinline__ void conv_tower_layer(const uint8_t* IN, const char* __restrict__& wb, uint32_t loff,
+                                                 s16x8 (&bq)[RT * 8][NT], f32x4 (&acc)[MT][NT], const int (&rinfo)[MT], int g16,
+                                                 int zero_row)
 {
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++) { acc[mt][0] = f32x4{0, 0, 0, 0}; acc[mt][1] = f32x4{0, 0, 0, 0}; }
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[mt][nt] = f32x4{0, 0, 0, 0};
     int aoff[MT];
     s16x8 a[2][MT];
 #pragma unroll
@@ -170,26 +180,26 @@ __device__ __forceinline__ void conv_tower_layer(const uint8_t* IN, const s16x8*
         a[0][mt] = *reinterpret_cast<const s16x8*>(IN + aoff[mt]);
     }
     if constexpr (RT == 1) {
-        for (int tap = 0; tap < 9; tap++) conv_tap<MT, 1, 0>(IN, tap, wcur, bq, acc, a, aoff, rinfo, g16, zero_row);
+        for (int tap = 0; tap < 9; tap++) conv_tap<MT, NT, 1, 0>(IN, tap, wb, loff, bq, acc, a, aoff, rinfo, g16, zero_row);
     } else {
         constexpr int S0 = PAR ? 8 : 0, S1 = PAR ? 0 : 8;
         for (int tap = 0; tap < 8; tap += 2) {
-            conv_tap<MT, 2, S0>(IN, tap, wcur, bq, acc, a, aoff, rinfo, g16, zero_row);
-            conv_tap<MT, 2, S1>(IN, tap + 1, wcur, bq, acc, a, aoff, rinfo, g16, zero_row);
+            conv_tap<MT, NT, 2, S0>(IN, tap, wb, loff, bq, acc, a, aoff, rinfo, g16, zero_row);
+            conv_tap<MT, NT, 2, S1>(IN, tap + 1, wb, loff, bq, acc, a, aoff, rinfo, g16, zero_row);
         }
-        conv_tap<MT, 2, S0>(IN, 8, wcur, bq, acc, a, aoff, rinfo, g16, zero_row);
+        conv_tap<MT, NT, 2, S0>(IN, 8, wb, loff, bq, acc, a, aoff, rinfo, g16, zero_row);
     }
 }
 
-template <int NB>
-__global__ __launch_bounds__(512, 2) void k_tower_bf16(const uint8_t* __restrict__ in88, int in_stride, int n,
-                                                       const uint16_t* __restrict__ stem_wp,
-                                                       const uint16_t* __restrict__ tower_wp,
-                                                       const float* __restrict__ fold, int blocks,
-                                                       uint16_t* __restrict__ out)
+template <int NB, int NT>
+__global__ __launch_bounds__(1024 / NT, NT == 2 ? 2 : 1) void k_tower_bf16(const uint8_t* __restrict__ in88, int in_stride, int n,
+                                                                           const uint16_t* __restrict__ stem_wp,
+                                                                           const uint16_t* __restrict__ tower_wp,
+                                                                           const float* __restrict__ fold, int blocks,
+                                                                           uint16_t* __restrict__ out)
 {
     using G = Geo<NB>;
-    constexpr int ROWS = G::ROWS, MT = G::MT;
+    constexpr int ROWS = G::ROWS, MT = G::MT, THREADS = 1024 / NT, WCOLS = NT * 16;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t* bufX = lds;
     uint8_t* bufT = lds + G::BUF;
@@ -199,17 +209,17 @@ __global__ __launch_bounds__(512, 2) void k_tower_bf16(const uint8_t* __restrict
     const int board0 = blockIdx.x * NB;
 
     // ---- stage the NNInputData images, zero the zero rows and the stem feature image
-    for (int i = tid; i < NB * 96; i += 512) {
+    for (int i = tid; i < NB * 96; i += THREADS) {
         const int b = i / 96, o = i % 96;
         in_l[i] = (board0 + b < n && o < 88) ? in88[(size_t)(board0 + b) * in_stride + o] : (uint8_t)0;
     }
-    for (int i = tid; i < ROWB / 4; i += 512) {
+    for (int i = tid; i < ROWB / 4; i += THREADS) {
         reinterpret_cast<uint32_t*>(bufX + ROWS * ROWB)[i] = 0;
         reinterpret_cast<uint32_t*>(bufT + ROWS * ROWB)[i] = 0;
     }
     __syncthreads();
     // stem features: bufT as [ROWS + 1][16] bf16 (row ROWS = zero row); planes 13..15 are zero
-    for (int i = tid; i < (ROWS + 1) * 16; i += 512) {
+    for (int i = tid; i < (ROWS + 1) * 16; i += THREADS) {
         const int r = i >> 4, c = i & 15;
         float v = 0.0f;
         if (r < ROWS) v = plane_value(in_l + (r / 42) * 96, r % 42, c);
@@ -225,31 +235,39 @@ __global__ __launch_bounds__(512, 2) void k_tower_bf16(const uint8_t* __restrict
         const int pos = r % 42, y = pos / 6, x = pos % 6;
         rinfo[mt] = r < ROWS ? (y | (x << 4) | (r << 8)) : (15 | (15 << 4) | (ROWS << 8));
     }
-    f32x4 acc[MT][2];
+    f32x4 acc[MT][NT];
 
-    // ---- start the weight ring: the first RING k-steps of layer 0 fly while the stem runs
-    const s16x8* __restrict__ wcur = reinterpret_cast<const s16x8*>(tower_wp) + (size_t)(wave * 2) * 64 + lane;
-    constexpr int RT = RingTaps<NB>::value;
-    s16x8 bq[RT * 8][2];
+    // ---- start the weight ring: the first ring of k-steps of layer 0 flies while the stem runs
+    const char* __restrict__ wb = reinterpret_cast<const char*>(tower_wp);      // wave-uniform, scalar-advanced
+    const uint32_t loff = (uint32_t)((wave * NT) * 64 + lane) * 16u;             // this lane's fragment bytes in a k-step
+    constexpr int RT = RingTaps<NB, NT>::value;
+    s16x8 bq[RT * 8][NT];
 #pragma unroll
-    for (int ks = 0; ks < RT * 8; ks++) { bq[ks][0] = wcur[ks * KSTRIDE]; bq[ks][1] = wcur[ks * KSTRIDE + 64]; }
+    for (int ks = 0; ks < RT * 8; ks++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) bq[ks][nt] = *reinterpret_cast<const s16x8*>(wb + ks * KBYTES + loff + nt * 1024);
 
     // ---- stem: 3x3 conv 13 -> 256, two taps per 32-deep k-step (tap slot = 2*ks + (g >> 1), channels (g & 1)*8 ..)
     {
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) { acc[mt][0] = f32x4{0, 0, 0, 0}; acc[mt][1] = f32x4{0, 0, 0, 0}; }
-        const s16x8* wp = reinterpret_cast<const s16x8*>(stem_wp) + (size_t)(wave * 2) * 64 + lane;
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[mt][nt] = f32x4{0, 0, 0, 0};
+        const s16x8* wp = reinterpret_cast<const s16x8*>(stem_wp) + (size_t)(wave * NT) * 64 + lane;
 #pragma unroll
         for (int ks = 0; ks < STEM_KS; ks++) {
             const int tap = 2 * ks + (g >> 1);
             const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            const s16x8 b0 = wp[(size_t)ks * FRAGS_PER_KSTEP * 64], b1 = wp[(size_t)ks * FRAGS_PER_KSTEP * 64 + 64];
+            s16x8 b[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) b[nt] = wp[(size_t)ks * FRAGS_PER_KSTEP * 64 + nt * 64];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
                 const int row = tap < 9 ? tap_row(rinfo[mt], dy, dx, ROWS) : ROWS;
-                const s16x8 a = *reinterpret_cast<const s16x8*>(bufT + row * FROWB + (g & 1) * 16);
-                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b0), acc[mt][0], 0, 0, 0);
-                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b1), acc[mt][1], 0, 0, 0);
+                const s16x8 av = *reinterpret_cast<const s16x8*>(bufT + row * FROWB + (g & 1) * 16);
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, b[nt]), acc[mt][nt], 0, 0, 0);
             }
         }
         // conv_bn over the board row + ReLU -> bufX   (C/D layout: col = lane & 15, row = (lane >> 4)*4 + j)
@@ -270,8 +288,8 @@ __global__ __launch_bounds__(512, 2) void k_tower_bf16(const uint8_t* __restrict
                 const int r = mt * 16 + g * 4 + j;
                 if (r < ROWS) {
 #pragma unroll
-                    for (int nt = 0; nt < 2; nt++) {
-                        const int co = wave * 32 + nt * 16 + m;
+                    for (int nt = 0; nt < NT; nt++) {
+                        const int co = wave * WCOLS + nt * 16 + m;
                         float v = fmaf(acc[mt][nt][j], rsc[mt][j], rsh[mt][j]);
                         reinterpret_cast<uint16_t*>(bufX + r * ROWB)[co] = bf_rne(v > 0.0f ? v : 0.0f);
                     }
@@ -282,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void k_tower_bf16(const uint8_t* __restrict
 
     // ---- residual tower: 2 conv layers per block, activations resident in LDS
     const int g16 = g * 16;
-    auto epilogue = [&](int layer, bool second, uint8_t* OUT, const float (&sc)[2], const float (&sh)[2]) {
+    auto epilogue = [&](bool second, uint8_t* OUT, const float (&sc)[NT], const float (&sh)[NT]) {
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -290,8 +308,8 @@ __global__ __launch_bounds__(512, 2) void k_tower_bf16(const uint8_t* __restrict
                 const int r = mt * 16 + g * 4 + j;
                 if (r < ROWS) {
 #pragma unroll
-                    for (int nt = 0; nt < 2; nt++) {
-                        const int co = wave * 32 + nt * 16 + m;
+                    for (int nt = 0; nt < NT; nt++) {
+                        const int co = wave * WCOLS + nt * 16 + m;
                         uint16_t* o = reinterpret_cast<uint16_t*>(OUT + r * ROWB) + co;
                         float v = fmaf(acc[mt][nt][j], sc[nt], sh[nt]);
                         if (second) v += bf2f(*o);  // shortcut: OUT still holds the block's input at this element
@@ -302,23 +320,23 @@ __global__ __launch_bounds__(512, 2) void k_tower_bf16(const uint8_t* __restrict
     };
     for (int blk = 0; blk < blocks; blk++) {
         // each layer's folded BN is requested before its taps so the epilogue never waits behind the weight ring
-        float sc[2], sh[2];
+        float sc[NT], sh[NT];
         const float* fs = fold + 14 + (size_t)(2 * blk) * 2 * NF;
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++) { sc[nt] = fs[wave * 32 + nt * 16 + m]; sh[nt] = fs[NF + wave * 32 + nt * 16 + m]; }
-        conv_tower_layer<MT, RT, 0>(bufX, wcur, bq, acc, rinfo, g16, ROWS);
-        epilogue(2 * blk, false, bufT, sc, sh);
+        for (int nt = 0; nt < NT; nt++) { sc[nt] = fs[wave * WCOLS + nt * 16 + m]; sh[nt] = fs[NF + wave * WCOLS + nt * 16 + m]; }
+        conv_tower_layer<MT, NT, RT, 0>(bufX, wb, loff, bq, acc, rinfo, g16, ROWS);
+        epilogue(false, bufT, sc, sh);
         __syncthreads();
         fs += 2 * NF;
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++) { sc[nt] = fs[wave * 32 + nt * 16 + m]; sh[nt] = fs[NF + wave * 32 + nt * 16 + m]; }
-        conv_tower_layer<MT, RT, 1>(bufT, wcur, bq, acc, rinfo, g16, ROWS);
-        epilogue(2 * blk + 1, true, bufX, sc, sh);
+        for (int nt = 0; nt < NT; nt++) { sc[nt] = fs[wave * WCOLS + nt * 16 + m]; sh[nt] = fs[NF + wave * WCOLS + nt * 16 + m]; }
+        conv_tower_layer<MT, NT, RT, 1>(bufT, wb, loff, bq, acc, rinfo, g16, ROWS);
+        epilogue(true, bufX, sc, sh);
         __syncthreads();
     }
 
     // ---- final activation -> HBM (bf16 [board][42][256]) for the heads kernel
-    for (int i = tid; i < ROWS * 32; i += 512) {
+    for (int i = tid; i < ROWS * 32; i += THREADS) {
         const int r = i >> 5, seg = i & 31;
         if (board0 + r / 42 < n) {
             const uint4 v = *reinterpret_cast<const uint4*>(bufX + r * ROWB + seg * 16);
@@ -346,9 +364,12 @@ int net_bf16_alloc(azr_engine* h)
     HIPCHK(h, hipMalloc((void**)&x->tower_wp, ((size_t)2 * B * TOWER_LAYER_HALFS + MAX_RING * KSTRIDE * 8) * 2));  // + ring run-off
     HIPCHK(h, hipMemsetAsync(x->tower_wp, 0, ((size_t)2 * B * TOWER_LAYER_HALFS + MAX_RING * KSTRIDE * 8) * 2, h->stream));
     HIPCHK(h, hipMalloc((void**)&x->act, (size_t)h->d.G * NPOS * NF * 2));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<1>::LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<2>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<2>::LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<3>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<3>::LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<1>::LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<2>::LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<3>::LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<1>::LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<2>::LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<3>::LDS_BYTES));
     return AZR_OK;
 }
 
@@ -407,17 +428,17 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
     const float* fold = net_fold(h);
     const int B = h->net.blocks;
     if (h->pe_tower0) hipEventRecord(h->pe_tower0, h->stream);
-    // boards per workgroup: fill the 256 CUs first, then grow the M tile
-    if (n <= 256) {
-        hipLaunchKernelGGL(k_tower_bf16<1>, dim3(n), dim3(512), Geo<1>::LDS_BYTES, h->stream, d_in88, in_stride, n,
-                           x->stem_wp, x->tower_wp, fold, B, x->act);
-    } else if (n <= 512) {
-        hipLaunchKernelGGL(k_tower_bf16<2>, dim3((n + 1) / 2), dim3(512), Geo<2>::LDS_BYTES, h->stream, d_in88, in_stride, n,
-                           x->stem_wp, x->tower_wp, fold, B, x->act);
-    } else {
-        hipLaunchKernelGGL(k_tower_bf16<3>, dim3((n + 2) / 3), dim3(512), Geo<3>::LDS_BYTES, h->stream, d_in88, in_stride, n,
-                           x->stem_wp, x->tower_wp, fold, B, x->act);
-    }
+    // boards per workgroup: fill the 256 CUs first, then grow the M tile.  Wave tiling: 8 waves x 32 channels by
+    // default; AZR_TOWER_NT=4 selects the 4-wave x 64-channel shape (measured equal at NB = 1, 2; slower at NB = 3).
+    static const int nt_env = getenv("AZR_TOWER_NT") ? atoi(getenv("AZR_TOWER_NT")) : 0;
+    const int NT = nt_env == 4 ? 4 : 2;
+#define LAUNCH_TOWER(NBV, NTV)                                                                                      \
+    hipLaunchKernelGGL((k_tower_bf16<NBV, NTV>), dim3((n + NBV - 1) / NBV), dim3(1024 / NTV), Geo<NBV>::LDS_BYTES, \
+                       h->stream, d_in88, in_stride, n, x->stem_wp, x->tower_wp, fold, B, x->act)
+    if (n <= 256) { if (NT == 2) LAUNCH_TOWER(1, 2); else LAUNCH_TOWER(1, 4); }
+    else if (n <= 512) { if (NT == 2) LAUNCH_TOWER(2, 2); else LAUNCH_TOWER(2, 4); }
+    else { if (NT == 2) LAUNCH_TOWER(3, 2); else LAUNCH_TOWER(3, 4); }
+#undef LAUNCH_TOWER
     if (h->pe_tower1) hipEventRecord(h->pe_tower1, h->stream);
     launch_heads_bf16(h->stream, n, x->act, net_head_params(h), d_pi, d_v);
     HIPCHK(h, hipGetLastError());
