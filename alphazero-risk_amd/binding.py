@@ -26,6 +26,17 @@ class Settings(C.Structure):
                 ("dir_noise_epsi", C.c_float), ("node_capacity", C.c_int32), ("sample_capacity", C.c_int32)]
 
 
+class GameResults(C.Structure):
+    """`azr_game_results` = GameResults (game/game.h:17-29)"""
+    _fields_ = [("count", C.c_int32), ("draw", C.c_int32), ("win", C.c_int32 * 2), ("win_and_started", C.c_int32 * 2)]
+
+    def as_dict(self):
+        return dict(count=self.count, draw=self.draw, win=list(self.win), win_and_started=list(self.win_and_started))
+
+
+PLAYER_ALPHAZERO, PLAYER_SCRIPT, PLAYER_RANDOM = 0, 1, 2
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("simulations", "evaluations", "levels", "decisions", "games_finished",
                                           "samples", "nodes_dropped", "errors")]
@@ -54,7 +65,7 @@ EXPORTS = [
     "azr_nn_predict", "azr_mcts_clear", "azr_mcts_trim", "azr_mcts_simulate", "azr_mcts_begin", "azr_mcts_leaves",
     "azr_mcts_apply", "azr_mcts_root_stats", "azr_mcts_policy", "azr_mcts_pick", "azr_selfplay_start", "azr_selfplay_run",
     "azr_selfplay_counters", "azr_samples_drain", "azr_samples_device_view", "azr_profile_last_run",
-    "azr_device_synchronize",
+    "azr_device_synchronize", "azr_arena_start", "azr_arena_run", "azr_arena_results", "azr_arena_log",
 ]
 
 
@@ -99,6 +110,10 @@ def load_library():
                      "azr_mcts_policy", "azr_selfplay_counters"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
         L.azr_engine_make_moves.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.azr_arena_start.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
+        L.azr_arena_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.azr_arena_results.argtypes = [C.c_void_p, C.c_void_p]
+        L.azr_arena_log.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -297,6 +312,28 @@ class Engine:
         a, b, k = C.c_float(0), C.c_float(0), C.c_int(0)
         self._chk(self.L.azr_profile_last_run(self.h, C.byref(a), C.byref(b), C.byref(k)))
         return dict(net_ms=a.value, tree_ms=b.value, launches=k.value)
+
+    # ---- arena (GameGroup::playGames)
+    def arena_start(self, player1, player2, games, per_slot_cap=0, mirror=True, base_seed=20260001):
+        self._chk(self.L.azr_arena_start(self.h, player1, player2, games, per_slot_cap, int(mirror), base_seed))
+
+    def arena_run(self, passes):
+        fin = C.c_int(0)
+        self._chk(self.L.azr_arena_run(self.h, passes, C.byref(fin)))
+        return bool(fin.value)
+
+    def arena_results(self):
+        r = GameResults()
+        self._chk(self.L.azr_arena_results(self.h, C.byref(r)))
+        return r.as_dict()
+
+    def arena_log(self):
+        n = np.zeros(self.G, np.int32)
+        st = np.zeros((self.G, 16), np.int8)
+        rd = np.zeros((self.G, 16), np.uint16)
+        fin = np.zeros((self.G, 16, 160), np.uint8)
+        self._chk(self.L.azr_arena_log(self.h, _p(n), _p(st), _p(rd), _p(fin)))
+        return n, st, rd, fin
 
     def synchronize(self):
         self._chk(self.L.azr_device_synchronize(self.h))

@@ -7,6 +7,7 @@
 #include <new>
 
 #include "azr_internal.hpp"
+#include "azr_players.hpp"
 
 using namespace azr;
 
@@ -38,11 +39,13 @@ __device__ __forceinline__ Tree tree_of(const Dev& E, int g)
 __device__ __forceinline__ void ctl_load(Ctl& c, const Ctl* src)
 {
     const uint32_t* p = reinterpret_cast<const uint32_t*>(src);
-    uint32_t w = p[lane_id() & 15u];
+    uint32_t w = p[lane_id() & 31u];
     c.mode = rdl(w, 0); c.search_id = rdl(w, 1); c.sims_done = rdl(w, 2); c.pending = rdl(w, 3);
     c.path_len = rdl(w, 4); c.nfree = rdl(w, 5); c.hiwater = rdl(w, 6); c.search_done = rdl(w, 7);
     c.rng = rdl(w, 8); c.game_no = rdl(w, 9); c.nsamples = rdl(w, 10); c.status = (int32_t)rdl(w, 11);
     c.error = rdl(w, 12); c.last_move = rdl(w, 13); c.decisions = rdl(w, 14); c.seed = rdl(w, 15);
+    c.arena_state = rdl(w, 16); c.player_start = rdl(w, 17); c.pair_phase = rdl(w, 18); c.turn_started = rdl(w, 19);
+    c.search_active = rdl(w, 20); c.slot_games = rdl(w, 21);
 }
 __device__ __forceinline__ void ctl_store(const Ctl& c, Ctl* dst)
 {
@@ -52,7 +55,9 @@ __device__ __forceinline__ void ctl_store(const Ctl& c, Ctl* dst)
     w = l == 4 ? c.path_len : w; w = l == 5 ? c.nfree : w; w = l == 6 ? c.hiwater : w; w = l == 7 ? c.search_done : w;
     w = l == 8 ? c.rng : w; w = l == 9 ? c.game_no : w; w = l == 10 ? c.nsamples : w; w = l == 11 ? (uint32_t)c.status : w;
     w = l == 12 ? c.error : w; w = l == 13 ? c.last_move : w; w = l == 14 ? c.decisions : w; w = l == 15 ? c.seed : w;
-    if (l < 16) reinterpret_cast<uint32_t*>(dst)[l] = w;
+    w = l == 16 ? c.arena_state : w; w = l == 17 ? c.player_start : w; w = l == 18 ? c.pair_phase : w;
+    w = l == 19 ? c.turn_started : w; w = l == 20 ? c.search_active : w; w = l == 21 ? c.slot_games : w;
+    if (l < 22) reinterpret_cast<uint32_t*>(dst)[l] = w;
 }
 
 // ================================================================================================
@@ -138,13 +143,13 @@ __global__ __launch_bounds__(64) void k_import160(Dev E, const uint8_t* data160)
     E.state[(size_t)g * GREC + l] = (uint8_t)b;
 }
 
-__global__ __launch_bounds__(64) void k_export160(Dev E, uint8_t* data160)
+__global__ __launch_bounds__(64) void k_export160(Dev E, const uint8_t* records, uint8_t* data160)
 {
     const int g = blockIdx.x;
     uint8_t* d = data160 + (size_t)g * 160;
     const uint32_t l = lane_id();
     WS s;
-    ws_load(s, E.state + (size_t)g * GREC);
+    ws_load(s, records + (size_t)g * GREC);
     for (uint32_t i = l; i < 160; i += 64) d[i] = 0;
     wave_mem_sync();
     if (l < LANDS) d[l] = (uint8_t)s.la;
@@ -238,96 +243,58 @@ __device__ __forceinline__ void flush_samples(const Dev& E, int g, uint32_t n, i
     }
 }
 
-// One tree step for game g: consume the pending leaf's (pi, v) [expand + backup], then run searches — and in
-// self-play mode decisions, moves and game restarts — until the next leaf that needs the net.
-template <bool SELFPLAY>
-__global__ __launch_bounds__(64) void k_tree_step(Dev E)
+struct StepCount {
+    unsigned long long sims = 0, evals = 0, levels = 0, dec = 0, games = 0, samples = 0, drop = 0, err = 0, ringdrop = 0;
+};
+
+__device__ __forceinline__ void flush_counters(const Dev& E, const Ctl& c, const StepCount& k)
 {
-    __shared__ int8_t scratch[128];
-    const int g = blockIdx.x;
-    Ctl c;
-    ctl_load(c, &E.ctl[g]);
-    if (c.mode == 0 || (!SELFPLAY && c.search_done)) return;
-    Tree t = tree_of(E, g);
+    if (lane_id() == 0) {
+        if (c.pending) atomicAdd(E.active, 1u);
+        Counters* o = E.counters;
+        if (k.sims) atomicAdd(&o->simulations, k.sims);
+        if (k.evals) atomicAdd(&o->evaluations, k.evals);
+        if (k.levels) atomicAdd(&o->levels, k.levels);
+        if (k.dec) atomicAdd(&o->decisions, k.dec);
+        if (k.games) atomicAdd(&o->games_finished, k.games);
+        if (k.samples) atomicAdd(&o->samples, k.samples);
+        if (k.drop) atomicAdd(&o->nodes_dropped, k.drop);
+        if (k.err) atomicAdd(&o->errors, k.err);
+        if (k.ringdrop) atomicAdd(&o->ring_dropped, k.ringdrop);
+    }
+}
+
+// AlphaZeroMCTS::search leaf branch, after the future resolved (alphazero_mcts.cpp:350-356): expand + backup
+__device__ __forceinline__ void consume_pending(const Dev& E, int g, const Tree& t, Ctl& c, StepCount& k)
+{
+    if (!c.pending) return;
+    const uint32_t l = lane_id();
+    float pi = E.net_pi[(size_t)g * PI_STRIDE + (l < MOVES ? l : 0)];
+    float v = rdlf(E.net_v[g], 0);
+    uint64_t valid = rfl64(E.leaf_valid[g]);
+    uint32_t kd = reinterpret_cast<const uint32_t*>(E.leaf_key + (size_t)g * GREC)[l & 15u];
+    uint32_t h = rfl(E.leaf_hash[g]);
+    float prior = normalize_prior(pi, valid);
+    if (tree_expand(t, c, kd, h, valid, prior) == NO_NODE) k.drop++;
+    k.evals++;
+    if (c.path_len > 0) {  // path_len == 0: this was setRootState's root expansion (not a simulation)
+        tree_backup(t, c.path_len, v);
+        c.sims_done++;
+        k.sims++;
+    }
+    c.pending = 0;
+}
+
+enum : int { RD_DONE = 0, RD_LEAF = 1, RD_FAIL = 2 };
+
+// AlphaZeroMCTS::search from the root (alphazero_mcts.cpp:322-377), iteratively, repeated until the search has its
+// S simulations (RD_DONE), a leaf needs the net (RD_LEAF: leaf record written, c.pending set) or a rule error (RD_FAIL).
+__device__ __forceinline__ int run_descents(const Dev& E, int g, const Tree& t, Ctl& c, const WS& root, int8_t* scratch,
+                                            StepCount& k, uint32_t& err_out)
+{
     const Rules R = E.rules;
     const Search S = E.search;
-    WS root;
-    ws_load(root, E.state + (size_t)g * GREC);
-    unsigned long long n_sims = 0, n_evals = 0, n_levels = 0, n_dec = 0, n_games = 0, n_samples = 0, n_drop = 0,
-                       n_err = 0, n_ringdrop = 0;
-    bool root_dirty = false;
-
-    if (c.pending) {  // AlphaZeroMCTS::search leaf branch, after the future resolved (alphazero_mcts.cpp:350-356)
-        const uint32_t l = lane_id();
-        float pi = E.net_pi[(size_t)g * PI_STRIDE + (l < MOVES ? l : 0)];
-        float v = rdlf(E.net_v[g], 0);
-        uint64_t valid = rfl64(E.leaf_valid[g]);
-        uint32_t kd = reinterpret_cast<const uint32_t*>(E.leaf_key + (size_t)g * GREC)[l & 15u];
-        uint32_t h = rfl(E.leaf_hash[g]);
-        float prior = normalize_prior(pi, valid);
-        if (tree_expand(t, c, kd, h, valid, prior) == NO_NODE) n_drop++;
-        n_evals++;
-        if (c.path_len > 0) {  // path_len == 0: this was setRootState's root expansion (not a simulation)
-            tree_backup(t, c.path_len, v);
-            c.sims_done++;
-            n_sims++;
-        }
-        c.pending = 0;
-    }
-
-    for (;;) {
-        if ((int)c.sims_done >= S.simulations) {
-            if (!SELFPLAY) { c.search_done = 1; break; }
-            // ---- one decision of the trainer's move loop (alphazero_trainer.cpp:91-112) ----
-            root.rng = c.rng;
-            uint32_t rkd = ws_record_dword(root);
-            uint32_t ridx = tree_lookup(t, rkd, key_hash(rkd));
-            uint32_t mv = NONE;
-            if (ridx != NO_NODE) {
-                const uint8_t* n = node_ptr(t, ridx);
-                const uint32_t l = lane_id();
-                uint32_t N = reinterpret_cast<const uint32_t*>(n + ND_N)[l < MOVES ? l : 0];
-                uint64_t valid = (uint64_t)rfl(*reinterpret_cast<const uint32_t*>(n + ND_VALID_LO)) |
-                                 ((uint64_t)rfl(*reinterpret_cast<const uint32_t*>(n + ND_VALID_HI)) << 32);
-                float pi = root_policy(N, valid);
-                mv = (int)root.round > S.temperature_threshold ? pick_highest(pi) : pick_random(root, pi);
-                if (c.nsamples < (uint32_t)E.SCAP) {
-                    uint8_t* rec = E.stage + ((size_t)g * E.SCAP + c.nsamples) * STAGE_BYTES;
-                    encode88(root, rec);
-                    if (l < MOVES) reinterpret_cast<float*>(rec + 88)[l] = pi;
-                    if (l == 0) rec[260] = (uint8_t)root.cur;
-                    c.nsamples++;
-                } else n_ringdrop++;
-            }
-            if (mv != NONE) make_move(root, mv, R); else root.err = E_LOGIC;
-            c.last_move = mv;
-            c.decisions++;
-            n_dec++;
-            int st = root.err ? ST_NOT_ENDED : game_status(root, R);
-            if (root.err || st != ST_NOT_ENDED) {
-                if (root.err) { n_err++; c.error = root.err; }
-                else {
-                    wave_mem_sync();
-                    flush_samples(E, g, c.nsamples, st, n_ringdrop);
-                    n_samples += c.nsamples;
-                    n_games++;
-                }
-                c.status = st;
-                // next game in this slot: seeds base + g, base + G + g, ...
-                c.game_no++;
-                c.seed = E.base_seed + c.game_no * (uint32_t)E.G + (uint32_t)g;
-                ws_blank(root);
-                root.rng = rng_seed(c.seed);
-                new_game(root);
-                c.nsamples = 0; c.decisions = 0;
-                tree_clear(t, c);
-            }
-            c.rng = root.rng;
-            root_dirty = true;
-            tree_trim(t, c);
-            c.sims_done = 0;
-        }
-        // ---- AlphaZeroMCTS::search from the root (alphazero_mcts.cpp:322-377), iteratively ----
+    while ((int)c.sims_done < S.simulations) {
         WS s = root;
         s.rng = c.rng;
         s.err = 0;
@@ -339,7 +306,7 @@ __global__ __launch_bounds__(64) void k_tree_step(Dev E)
                 float v = gs == ST_DRAW ? 0.0f : (gs == (int)s.cur ? 1.0f : -1.0f);
                 tree_backup(t, plen, v);
                 c.sims_done++;
-                n_sims++;
+                k.sims++;
                 break;
             }
             uint64_t valid = valid_moves(s, R);
@@ -355,7 +322,7 @@ __global__ __launch_bounds__(64) void k_tree_step(Dev E)
                 leaf = true;
                 break;
             }
-            n_levels++;
+            k.levels++;
             uint32_t mv = tree_select(t, idx, S, c.search_id, scratch);
             if (mv == NONE) { fail = true; s.err = E_LOGIC; break; }
             uint32_t before = s.cur;
@@ -366,18 +333,111 @@ __global__ __launch_bounds__(64) void k_tree_step(Dev E)
             plen++;
         }
         c.rng = s.rng;
-        if (fail) {
-            n_err++;
-            c.error = s.err;
+        if (fail) { err_out = s.err; return RD_FAIL; }
+        if (leaf) {
+            c.pending = 1;
+            c.path_len = plen;
+            return RD_LEAF;
+        }
+    }
+    return RD_DONE;
+}
+
+// N[lane] and the legal mask of the node of `root` (NO_NODE if the root is not in the tree)
+__device__ __forceinline__ uint32_t root_node(const Tree& t, const WS& root, uint32_t& N, uint64_t& valid)
+{
+    uint32_t rkd = ws_record_dword(root);
+    uint32_t ridx = tree_lookup(t, rkd, key_hash(rkd));
+    N = 0; valid = 0;
+    if (ridx != NO_NODE) {
+        const uint8_t* n = node_ptr(t, ridx);
+        const uint32_t l = lane_id();
+        N = reinterpret_cast<const uint32_t*>(n + ND_N)[l < MOVES ? l : 0];
+        valid = (uint64_t)rfl(*reinterpret_cast<const uint32_t*>(n + ND_VALID_LO)) |
+                ((uint64_t)rfl(*reinterpret_cast<const uint32_t*>(n + ND_VALID_HI)) << 32);
+    }
+    return ridx;
+}
+
+// the slot's next self-play game: seeds base + g, base + G + g, ...
+__device__ __forceinline__ void selfplay_next_game(const Dev& E, int g, const Tree& t, Ctl& c, WS& root)
+{
+    c.game_no++;
+    c.seed = E.base_seed + c.game_no * (uint32_t)E.G + (uint32_t)g;
+    ws_blank(root);
+    root.rng = rng_seed(c.seed);
+    new_game(root);
+    c.rng = root.rng;
+    c.nsamples = 0; c.decisions = 0; c.sims_done = 0;
+    tree_clear(t, c);
+}
+
+// One tree step for game g: consume the pending leaf's (pi, v) [expand + backup], then run searches — and in
+// self-play mode decisions, moves and game restarts — until the next leaf that needs the net.
+template <bool SELFPLAY>
+__global__ __launch_bounds__(64) void k_tree_step(Dev E)
+{
+    __shared__ int8_t scratch[128];
+    const int g = blockIdx.x;
+    Ctl c;
+    ctl_load(c, &E.ctl[g]);
+    if (c.mode == 0 || (!SELFPLAY && c.search_done)) return;
+    Tree t = tree_of(E, g);
+    const Rules R = E.rules;
+    const Search S = E.search;
+    WS root;
+    ws_load(root, E.state + (size_t)g * GREC);
+    StepCount k;
+    bool root_dirty = false;
+    consume_pending(E, g, t, c, k);
+    for (;;) {
+        if ((int)c.sims_done >= S.simulations) {
+            if (!SELFPLAY) { c.search_done = 1; break; }
+            // ---- one decision of the trainer's move loop (alphazero_trainer.cpp:91-112) ----
+            root.rng = c.rng;
+            uint32_t N; uint64_t valid;
+            uint32_t mv = NONE;
+            if (root_node(t, root, N, valid) != NO_NODE) {
+                const uint32_t l = lane_id();
+                float pi = root_policy(N, valid);
+                mv = (int)root.round > S.temperature_threshold ? pick_highest(pi) : pick_random(root, pi);
+                if (c.nsamples < (uint32_t)E.SCAP) {
+                    uint8_t* rec = E.stage + ((size_t)g * E.SCAP + c.nsamples) * STAGE_BYTES;
+                    encode88(root, rec);
+                    if (l < MOVES) reinterpret_cast<float*>(rec + 88)[l] = pi;
+                    if (l == 0) rec[260] = (uint8_t)root.cur;
+                    c.nsamples++;
+                } else k.ringdrop++;
+            }
+            if (mv != NONE) make_move(root, mv, R); else root.err = E_LOGIC;
+            c.last_move = mv;
+            c.decisions++;
+            k.dec++;
+            c.rng = root.rng;
+            int st = root.err ? ST_NOT_ENDED : game_status(root, R);
+            if (root.err || st != ST_NOT_ENDED) {
+                if (root.err) { k.err++; c.error = root.err; }
+                else {
+                    wave_mem_sync();
+                    flush_samples(E, g, c.nsamples, st, k.ringdrop);
+                    k.samples += c.nsamples;
+                    k.games++;
+                }
+                c.status = st;
+                selfplay_next_game(E, g, t, c, root);
+            }
+            root_dirty = true;
+            tree_trim(t, c);
+            c.sims_done = 0;
+        }
+        uint32_t err = 0;
+        int r = run_descents(E, g, t, c, root, scratch, k, err);
+        if (r == RD_LEAF) break;
+        if (r == RD_FAIL) {
+            k.err++;
+            c.error = err;
             if (SELFPLAY) {  // abandon the game (the reference would have thrown): restart the slot
-                c.game_no++;
-                c.seed = E.base_seed + c.game_no * (uint32_t)E.G + (uint32_t)g;
-                ws_blank(root);
-                root.rng = rng_seed(c.seed);
-                new_game(root);
-                c.rng = root.rng;
-                c.nsamples = 0; c.decisions = 0; c.sims_done = 0;
-                tree_clear(t, c);
+                selfplay_next_game(E, g, t, c, root);
                 tree_trim(t, c);
                 root_dirty = true;
                 continue;
@@ -385,27 +445,150 @@ __global__ __launch_bounds__(64) void k_tree_step(Dev E)
             c.search_done = 1;
             break;
         }
-        if (leaf) {
-            c.pending = 1;
-            c.path_len = plen;
-            break;
-        }
     }
     if (root_dirty) ws_store(root, E.state + (size_t)g * GREC);
     ctl_store(c, &E.ctl[g]);
-    if (lane_id() == 0) {
-        if (c.pending) atomicAdd(E.active, 1u);
-        Counters* k = E.counters;
-        if (n_sims) atomicAdd(&k->simulations, n_sims);
-        if (n_evals) atomicAdd(&k->evaluations, n_evals);
-        if (n_levels) atomicAdd(&k->levels, n_levels);
-        if (n_dec) atomicAdd(&k->decisions, n_dec);
-        if (n_games) atomicAdd(&k->games_finished, n_games);
-        if (n_samples) atomicAdd(&k->samples, n_samples);
-        if (n_drop) atomicAdd(&k->nodes_dropped, n_drop);
-        if (n_err) atomicAdd(&k->errors, n_err);
-        if (n_ringdrop) atomicAdd(&k->ring_dropped, n_ringdrop);
+    flush_counters(E, c, k);
+}
+
+// ================================================================================================
+// arena: GameGroup::playGames on the device (game/game.cpp:101-312).  One slot = one player pair = one "thread" of
+// the reference: games in mirrored pairs with alternating starts, AlphaZeroPlayer::takeTurn (alphazero_player.cpp:3-21)
+// through the search above, ScriptPlayer / RandomPlayer as wave-resident code (azr_players.hpp).
+// ================================================================================================
+__global__ __launch_bounds__(64) void k_arena_step(Dev E)
+{
+    __shared__ int8_t scratch[128];
+    const int g = blockIdx.x;
+    Ctl c;
+    ctl_load(c, &E.ctl[g]);
+    if (c.mode != 3 || c.arena_state == 2) return;
+    Tree t = tree_of(E, g);
+    const Rules R = E.rules;
+    const Search S = E.search;
+    WS root;
+    ws_load(root, E.state + (size_t)g * GREC);
+    root.rng = c.rng;
+    ScriptW sp[2];
+    {
+        const ScriptW* src = reinterpret_cast<const ScriptW*>(E.script) + (size_t)g * 2;
+        sp[0] = src[0]; sp[1] = src[1];
+        sp[0].order = rfl(sp[0].order); sp[0].attacking_set = rfl(sp[0].attacking_set); sp[0].land_to = rfl(sp[0].land_to);
+        sp[0].land_from = rfl(sp[0].land_from); sp[0].attack_from_army = rfl(sp[0].attack_from_army);
+        sp[1].order = rfl(sp[1].order); sp[1].attacking_set = rfl(sp[1].attacking_set); sp[1].land_to = rfl(sp[1].land_to);
+        sp[1].land_from = rfl(sp[1].land_from); sp[1].attack_from_army = rfl(sp[1].attack_from_army);
     }
+    StepCount k;
+    consume_pending(E, g, t, c, k);
+    for (;;) {
+        if (c.arena_state == 0) {  // Game::newGame (game.cpp:170-191) for the next Game::playGames(1)
+            if (c.pair_phase == 0) {  // Counter::hasNext(2) (game.cpp:14-26)
+                int taken = 0;
+                const bool capped = E.arena_slot_cap > 0 && (int)c.slot_games >= E.arena_slot_cap;
+                if (!capped && lane_id() == 0) taken = atomicAdd(E.arena_taken, 2);
+                taken = (int)rfl((uint32_t)taken);
+                if (capped || taken + 2 > E.arena_total) { c.arena_state = 2; break; }
+            }
+            if (E.arena_mirror && c.player_start != 0) {
+                uint32_t keep = root.rng;
+                ws_load(root, E.prev_start + (size_t)g * GREC);
+                root.rng = keep;
+                invert_players(root);
+                root.cur = c.player_start;
+            } else {
+                new_game(root);
+                root.cur = c.player_start;
+                ws_store(root, E.prev_start + (size_t)g * GREC);
+            }
+            tree_clear(t, c);  // AlphaZeroPlayer::newGame
+            c.sims_done = 0; c.search_active = 0; c.turn_started = 0; c.pending = 0; c.path_len = 0;
+            c.arena_state = 1;
+        }
+        // ---- Game::playTurn (game.cpp:112-133)
+        int gs = game_status(root, R);
+        if (gs != ST_NOT_ENDED) {  // GameResults::addGame (game.cpp:193-213)
+            if (lane_id() == 0) {
+                atomicAdd(&E.arena_res[0], 1);
+                if (gs == ST_DRAW) atomicAdd(&E.arena_res[1], 1);
+                if (gs == 0 || gs == 1) {
+                    atomicAdd(&E.arena_res[2 + 2 * gs], 1);
+                    if ((int)c.player_start == gs) atomicAdd(&E.arena_res[3 + 2 * gs], 1);
+                }
+                if (c.slot_games < (uint32_t)ALOG) {
+                    E.alog_status[(size_t)g * ALOG + c.slot_games] = (int8_t)gs;
+                    E.alog_rounds[(size_t)g * ALOG + c.slot_games] = (uint16_t)root.round;
+                }
+            }
+            if (c.slot_games < (uint32_t)ALOG) ws_store(root, E.alog_final + ((size_t)g * ALOG + c.slot_games) * GREC);
+            c.slot_games++;
+            k.games++;
+            c.player_start ^= 1u;  // Game::incPlayerStart
+            c.pair_phase ^= 1u;
+            c.arena_state = 0;
+            continue;
+        }
+        const uint32_t p = root.cur;
+        const int kind = p == 0 ? E.kind0 : E.kind1;
+        bool fail = false;
+        if (kind == 1) {
+            if (p == 0) script_take_turn(sp[0], root, R); else script_take_turn(sp[1], root, R);
+            fail = root.err != 0 || (root.cur == p && game_status(root, R) == ST_NOT_ENDED);  // "Turn was not incremented"
+        } else if (kind == 2) {
+            random_take_turn(root, R);
+            fail = root.err != 0 || (root.cur == p && game_status(root, R) == ST_NOT_ENDED);
+        } else {
+            if (!c.turn_started) { tree_trim(t, c); c.turn_started = 1; }   // the player's own trimNodes
+            if (!c.search_active) { tree_trim(t, c); c.sims_done = 0; c.search_active = 1; }  // simulate -> setRootState
+            c.rng = root.rng;
+            uint32_t err = 0;
+            int r = run_descents(E, g, t, c, root, scratch, k, err);
+            root.rng = c.rng;
+            if (r == RD_LEAF) break;
+            if (r == RD_FAIL) { fail = true; root.err = err; }
+            else {
+                uint32_t N; uint64_t valid;
+                uint32_t mv = NONE;
+                if (root_node(t, root, N, valid) != NO_NODE) mv = pick_highest(root_policy(N, valid));
+                if (mv != NONE) make_move(root, mv, R); else root.err = E_LOGIC;
+                c.search_active = 0;
+                c.last_move = mv;
+                k.dec++;
+                fail = root.err != 0;
+                if (root.cur != p || game_status(root, R) != ST_NOT_ENDED) c.turn_started = 0;
+            }
+        }
+        if (fail) {  // the reference would have thrown out of GameGroup: drop the game, start a fresh pair
+            k.err++;
+            c.error = root.err ? root.err : (uint32_t)E_LOGIC;
+            root.err = 0;
+            c.player_start = 0; c.pair_phase = 0; c.arena_state = 0;
+        }
+    }
+    c.rng = root.rng;
+    ws_store(root, E.state + (size_t)g * GREC);
+    {
+        ScriptW* dst = reinterpret_cast<ScriptW*>(E.script) + (size_t)g * 2;
+        if (lane_id() == 0) { dst[0] = sp[0]; dst[1] = sp[1]; }
+    }
+    ctl_store(c, &E.ctl[g]);
+    flush_counters(E, c, k);
+}
+
+__global__ __launch_bounds__(64) void k_arena_start(Dev E)
+{
+    const int g = blockIdx.x;
+    Ctl c;
+    ctl_load(c, &E.ctl[g]);
+    Tree t = tree_of(E, g);
+    c.hiwater = (uint32_t)E.C;
+    tree_clear(t, c);
+    c.mode = 3; c.sims_done = 0; c.pending = 0; c.path_len = 0; c.search_done = 0; c.error = 0;
+    c.arena_state = 0; c.player_start = 0; c.pair_phase = 0; c.turn_started = 0; c.search_active = 0; c.slot_games = 0;
+    c.seed = E.base_seed + (uint32_t)g;
+    c.rng = rng_seed(c.seed);
+    ScriptW* dst = reinterpret_cast<ScriptW*>(E.script) + (size_t)g * 2;
+    if (lane_id() == 0) { ScriptW w; script_init(w); dst[0] = w; dst[1] = w; }
+    ctl_store(c, &E.ctl[g]);
 }
 
 // root statistics / policy / pick for host-stepped use
@@ -565,6 +748,13 @@ extern "C" int azr_engine_create(const azr_settings* s, azr_engine** out)
     HIPCHK(h, dmalloc(&d.ring_count, 1));
     HIPCHK(h, dmalloc(&d.counters, 1));
     HIPCHK(h, dmalloc(&d.active, 1));
+    HIPCHK(h, dmalloc(&d.arena_taken, 1));
+    HIPCHK(h, dmalloc(&d.arena_res, 8));
+    HIPCHK(h, dmalloc(&d.prev_start, G * GREC));
+    HIPCHK(h, dmalloc(&d.script, G * 2 * 32));
+    HIPCHK(h, dmalloc(&d.alog_status, G * ALOG));
+    HIPCHK(h, dmalloc(&d.alog_rounds, G * ALOG));
+    HIPCHK(h, dmalloc(&d.alog_final, G * ALOG * GREC));
     HIPCHK(h, hipMemsetAsync(d.state, 0, G * GREC, h->stream));
     HIPCHK(h, hipMemsetAsync(d.ctl, 0, G * sizeof(Ctl), h->stream));
     HIPCHK(h, hipMemsetAsync(d.touch, 0, G * C * sizeof(uint32_t), h->stream));
@@ -590,7 +780,8 @@ extern "C" int azr_engine_destroy(azr_engine* h)
     hipStreamSynchronize(h->stream);
     Dev& d = h->d;
     void* ptrs[] = {d.state, d.ctl, d.nodes, d.touch, d.nhash, d.table, d.freel, d.path, d.leaf_in, d.leaf_key,
-                    d.leaf_valid, d.leaf_hash, d.net_pi, d.net_v, d.stage, d.ring, d.ring_count, d.counters, d.active};
+                    d.leaf_valid, d.leaf_hash, d.net_pi, d.net_v, d.stage, d.ring, d.ring_count, d.counters, d.active,
+                    d.arena_taken, d.arena_res, d.prev_start, d.script, d.alog_status, d.alog_rounds, d.alog_final};
     for (void* p : ptrs) if (p) hipFree(p);
     net_free(h);
     for (hipEvent_t e : h->ev) hipEventDestroy(e);
@@ -651,7 +842,7 @@ extern "C" int azr_engine_get_states(azr_engine* h, void* data160)
     if (!data160) return AZR_E_INVALID_ARGUMENT;
     DevBuf b;
     HIPCHK(h, b.alloc((size_t)h->d.G * 160));
-    LAUNCH(h, k_export160, h->d, (uint8_t*)b.p);
+    LAUNCH(h, k_export160, h->d, (const uint8_t*)h->d.state, (uint8_t*)b.p);
     D2H(h, data160, b.p, (size_t)h->d.G * 160);
     SYNC(h);
     return AZR_OK;
@@ -968,6 +1159,86 @@ extern "C" int azr_samples_device_view(azr_engine* h, void** dev_ptr, size_t* n_
 extern "C" int azr_device_synchronize(azr_engine* h)
 {
     ENTER(h);
+    SYNC(h);
+    return AZR_OK;
+}
+
+// ---- arena: GameGroup::playGames (game/game.cpp:256-312) ----------------------------------------------------------
+extern "C" int azr_arena_start(azr_engine* h, int player1, int player2, int games, int games_per_slot_cap, int mirror_games,
+                               uint32_t base_seed)
+{
+    ENTER(h);
+    if (player1 < 0 || player1 > 2 || player2 < 0 || player2 > 2 || games < 0) return AZR_E_INVALID_ARGUMENT;
+    if (player1 == AZR_PLAYER_ALPHAZERO && player2 == AZR_PLAYER_ALPHAZERO) {
+        h->err = "azr_arena_start: AlphaZero vs AlphaZero needs two trees per slot (not built yet)";
+        return AZR_E_STATE;
+    }
+    if ((player1 == AZR_PLAYER_ALPHAZERO || player2 == AZR_PLAYER_ALPHAZERO) && !h->weights_set) {
+        h->err = "azr_arena_start: no weights";
+        return AZR_E_STATE;
+    }
+    Dev& d = h->d;
+    d.kind0 = player1; d.kind1 = player2; d.arena_total = games; d.arena_slot_cap = games_per_slot_cap;
+    d.arena_mirror = mirror_games; d.base_seed = base_seed;
+    h->mode = 3;
+    HIPCHK(h, hipMemsetAsync(d.arena_taken, 0, sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(d.arena_res, 0, 8 * sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(d.counters, 0, sizeof(Counters), h->stream));
+    HIPCHK(h, hipMemsetAsync(d.alog_status, 0, (size_t)d.G * ALOG, h->stream));
+    LAUNCH(h, k_arena_start, d);
+    SYNC(h);
+    return AZR_OK;
+}
+
+extern "C" int azr_arena_run(azr_engine* h, int passes, int* finished_out)
+{
+    ENTER(h);
+    if (h->mode != 3) { h->err = "azr_arena_run: call azr_arena_start first"; return AZR_E_STATE; }
+    const bool needs_net = h->d.kind0 == AZR_PLAYER_ALPHAZERO || h->d.kind1 == AZR_PLAYER_ALPHAZERO;
+    for (int p = 0; p < passes; p++) {
+        LAUNCH(h, k_arena_step, h->d);
+        if (needs_net) {
+            int rc = net_forward(h, h->d.leaf_in, LEAF_STRIDE, h->d.G, h->d.net_pi, h->d.net_v);
+            if (rc) return rc;
+        }
+    }
+    std::vector<uint32_t> st(h->d.G);
+    HIPCHK(h, hipMemcpy2DAsync(st.data(), 4, &h->d.ctl[0].arena_state, sizeof(Ctl), 4, h->d.G, hipMemcpyDeviceToHost, h->stream));
+    SYNC(h);
+    int idle = 0;
+    for (uint32_t v : st) idle += v == 2;
+    if (finished_out) *finished_out = idle == h->d.G;
+    return AZR_OK;
+}
+
+extern "C" int azr_arena_results(azr_engine* h, azr_game_results* out)
+{
+    ENTER(h);
+    if (!out) return AZR_E_INVALID_ARGUMENT;
+    int r[8];
+    D2H(h, r, h->d.arena_res, sizeof r);
+    SYNC(h);
+    out->count = r[0]; out->draw = r[1]; out->win[0] = r[2]; out->win_and_started[0] = r[3];
+    out->win[1] = r[4]; out->win_and_started[1] = r[5];
+    return AZR_OK;
+}
+
+extern "C" int azr_arena_log(azr_engine* h, int32_t* games_per_slot, int8_t* status, uint16_t* rounds, void* finals160)
+{
+    ENTER(h);
+    const int G = h->d.G;
+    if (games_per_slot)
+        HIPCHK(h, hipMemcpy2DAsync(games_per_slot, 4, &h->d.ctl[0].slot_games, sizeof(Ctl), 4, G, hipMemcpyDeviceToHost, h->stream));
+    if (status) D2H(h, status, h->d.alog_status, (size_t)G * ALOG);
+    if (rounds) D2H(h, rounds, h->d.alog_rounds, (size_t)G * ALOG * 2);
+    if (finals160) {
+        DevBuf b;
+        HIPCHK(h, b.alloc((size_t)G * ALOG * 160));
+        hipLaunchKernelGGL(k_export160, dim3(G * ALOG), dim3(64), 0, h->stream, h->d, (const uint8_t*)h->d.alog_final, (uint8_t*)b.p);
+        HIPCHK(h, hipGetLastError());
+        D2H(h, finals160, b.p, (size_t)G * ALOG * 160);
+        SYNC(h);
+    }
     SYNC(h);
     return AZR_OK;
 }

@@ -43,7 +43,20 @@ struct Dev {
     Counters* counters;
     uint32_t* active;      // number of games with a pending leaf after the last tree step
     uint32_t base_seed;
+    // arena (GameGroup::playGames, game/game.cpp:277-312)
+    int kind0, kind1;          // AZR_PLAYER_* of player index 0 / 1
+    int arena_total;           // Counter::count
+    int arena_slot_cap;        // optional cap of games per slot (0 = none)
+    int arena_mirror;          // SETTINGS.MIRROR_GAMES
+    int* arena_taken;          // Counter::i
+    int* arena_res;            // GameResults: count, draw, win0, winStarted0, win1, winStarted1
+    uint8_t* prev_start;       // [G][64]  Game::previousStartState
+    uint8_t* script;           // [G][2][32]  ScriptW
+    int8_t* alog_status;       // [G][ALOG]
+    uint16_t* alog_rounds;     // [G][ALOG]
+    uint8_t* alog_final;       // [G][ALOG][64]
 };
+constexpr int ALOG = 16;
 
 // folded network parameters on device
 struct NetDev {

@@ -44,7 +44,14 @@ struct alignas(128) Ctl {
     uint32_t last_move;
     uint32_t decisions;    // decisions taken in the running game
     uint32_t seed;         // seed of the running game
-    uint32_t pad[16];
+    // arena mode (game/game.cpp): the slot is one "thread" of GameGroup::playGames
+    uint32_t arena_state;  // 0 = needs Game::newGame | 1 = playing | 2 = idle (quota exhausted)
+    uint32_t player_start; // Game::playerStart
+    uint32_t pair_phase;   // 0 = first game of a pair (Counter::hasNext(2) taken here) | 1 = second
+    uint32_t turn_started; // AlphaZeroPlayer::takeTurn in progress (its own trimNodes done)
+    uint32_t search_active;// AlphaZeroMCTS::simulate in progress
+    uint32_t slot_games;   // games finished in this slot
+    uint32_t pad[10];
 };
 static_assert(sizeof(Ctl) == 128, "Ctl must be one line");
 

@@ -144,6 +144,25 @@ int azr_samples_drain(azr_engine* h, void* rec265_host, size_t cap_records, size
  * azr_selfplay_run / azr_samples_drain */
 int azr_samples_device_view(azr_engine* h, void** dev_ptr_out, size_t* n_out);
 
+/* ---- arena: GameGroup::playGames (game/game.cpp:256-312) on the device ------------------------------------------------ */
+/* The G slots of the engine are the reference's G player pairs (threads): each plays Game::playGames(1) repeatedly —
+ * mirrored pairs with alternating starts (Game::newGame, game.cpp:170-191) — until Counter::hasNext(2) fails.
+ * Players: AlphaZeroPlayer (alphazero_player.cpp:3-21, argmax, tree trimmed at every turn), ScriptPlayer
+ * (player/script/script_player.cpp), RandomPlayer (player/random/random_player.cpp). */
+enum { AZR_PLAYER_ALPHAZERO = 0, AZR_PLAYER_SCRIPT = 1, AZR_PLAYER_RANDOM = 2 };
+typedef struct azr_game_results {   /* GameResults (game/game.h:17-29) */
+    int32_t count, draw;
+    int32_t win[2], win_and_started[2];
+} azr_game_results;
+/* games = Counter::count; games_per_slot_cap > 0 additionally limits every slot (deterministic splits for tests) */
+int azr_arena_start(azr_engine* h, int player1, int player2, int games, int games_per_slot_cap, int mirror_games,
+                    uint32_t base_seed);
+int azr_arena_run(azr_engine* h, int passes, int* finished_out);
+int azr_arena_results(azr_engine* h, azr_game_results* out);
+/* per slot: games finished, and for its first 16 games status / round count / final state image */
+int azr_arena_log(azr_engine* h, int32_t* games_per_slot_host, int8_t* status_host /*[G][16]*/,
+                  uint16_t* rounds_host /*[G][16]*/, void* finals160_host /*[G][16][160]*/);
+
 /* ---- measurement hooks (bench.py) --------------------------------------------------------------------------- */
 /* average duration in ms of the net-forward launches and of the tree-step launches over the last
  * azr_selfplay_run, measured with HIP events on the engine's stream */

@@ -1525,3 +1525,345 @@ int orc_bench_selfplay(const orc_settings* cfg, const orc_net* net, uint32_t bas
     *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     return 0;
 }
+
+/* ================================================================================================
+ * Opponent players and the host game driver: ScriptPlayer (player/script/script_player.cpp),
+ * RandomPlayer (player/random/random_player.cpp), Game / GameResults (game/game.cpp:101-235).  PINNED against the
+ * real reference (these units are TensorFlow-free and are part of oracle/_ref).
+ * ============================================================================================== */
+
+/* LandSet constructor orders (land/land_set.cpp:12-33); priority vector initial order of ScriptPlayer() is
+ * ASIA, NORTH_AMERICA, SOUTH_AMERICA, EUROPE, AFRICA, AUSTRALIA (script_player.cpp:12-14) */
+static const uint8_t SET_LANDS[6][12] = {
+    {26, 33, 35, 36, 27, 28, 29, 30, 31, 32, 34, 37},      /* ASIA */
+    {0, 1, 2, 3, 4, 5, 6, 7, 8},                           /* NORTH_AMERICA */
+    {9, 10, 11, 12},                                       /* SOUTH_AMERICA */
+    {13, 14, 15, 16, 17, 19, 18},                          /* EUROPE */
+    {20, 21, 22, 24, 25, 23},                              /* AFRICA */
+    {38, 39, 40, 41},                                      /* AUSTRALIA */
+};
+static const uint8_t SET_COUNT[6] = {12, 9, 4, 7, 6, 4};
+static const uint64_t SET_MASK[6] = {0x3ffc000000ULL, 0x1ffULL, 0x1e00ULL, 0xfe000ULL, 0x3f00000ULL, 0x3c000000000ULL};
+
+int orc_landset_lands(int set, uint8_t* out12) { memcpy(out12, SET_LANDS[set], SET_COUNT[set]); return SET_COUNT[set]; }
+
+void orc_script_init(orc_script* p)
+{
+    memset(p, 0, sizeof *p);
+    for (int i = 0; i < 6; i++) p->order[i] = (uint8_t)i;
+    p->attacking_set = -1;
+    p->land_to = ORC_NONE;
+    p->land_from = ORC_NONE;
+}
+
+/* GameHelper::sortLandSet (game_helper.cpp:19-39): strict weak order that is total (mask tie-break) */
+static int landset_before(const orc_script* p, int a, int b)
+{
+    if (p->not_owned[a] == p->not_owned[b]) {
+        if (p->not_owned_attack[a] == p->not_owned_attack[b]) return SET_MASK[a] > SET_MASK[b];
+        return p->not_owned_attack[a] > p->not_owned_attack[b];
+    }
+    return p->not_owned[a] < p->not_owned[b];
+}
+
+/* ScriptPlayer::updateAttackLandSetPriority / updateAttackLandSet / updateAttackLandTo / updateAttackLandFrom
+ * (script_player.cpp:17-80) */
+static void script_update(orc_script* p, const orc_state* s)
+{
+    const orc_player* ps = &s->ps[s->cur];
+    for (int k = 0; k < 6; k++) {
+        uint64_t no = SET_MASK[k] & ~ps->owned;
+        p->not_owned[k] = (uint8_t)popc(no);
+        p->not_owned_attack[k] = (uint8_t)popc(no & p->attack_mask);
+    }
+    for (int i = 1; i < 6; i++) { /* std::sort on 6 elements == insertion sort; the order is total */
+        uint8_t v = p->order[i];
+        int j = i;
+        while (j > 0 && landset_before(p, v, p->order[j - 1])) { p->order[j] = p->order[j - 1]; j--; }
+        p->order[j] = v;
+    }
+    for (int i = 0; i < 6; i++)
+        if (p->not_owned_attack[p->order[i]] > 0) { p->attacking_set = p->order[i]; break; }
+    if (p->attacking_set >= 0) {
+        int k = p->attacking_set;
+        for (int i = 0; i < SET_COUNT[k]; i++)
+            if (((1ULL << SET_LANDS[k][i]) & p->attack_mask) > 0) { p->land_to = SET_LANDS[k][i]; break; }
+    }
+    p->attack_from_army = 0;
+    if (p->land_to != ORC_NONE)
+        for (int i = 0; i < LAND[p->land_to].n; i++) {
+            int nl = LAND[p->land_to].nb[i];
+            if ((1ULL << nl) & p->owned_attack_mask) {
+                if (s->army[nl] > p->attack_from_army) { p->attack_from_army = s->army[nl]; p->land_from = nl; }
+            }
+        }
+}
+
+/* ScriptPlayer::attackLand (script_player.cpp:82-135) */
+static int script_attack_land(orc_script* p, orc_state* s, orc_rng* r, const orc_settings* cfg)
+{
+    if (p->land_from == ORC_NONE || p->land_to == ORC_NONE) return ORC_LOGIC_ERROR; /* null deref in the reference */
+    while (s->reinf > 0) {
+        const orc_player* ps = &s->ps[s->cur];
+        uint64_t not_full = ps->owned & ~ps->owned_full;
+        int to = p->land_from;
+        if (((1ULL << p->land_from) & not_full) == 0) {
+            uint64_t nb = nb_mask(p->land_to) & not_full;
+            if (nb > 0) to = ctz(nb);
+            else {
+                nb = not_full & (cenemy_ps(s)->attack | neutral_attack_lands(s));
+                if (nb > 0) to = ctz(nb);
+                else to = ctz(not_full); /* not_full == 0: lm2li(garbage) in the reference */
+            }
+        }
+        uint8_t max_reinf = (uint8_t)(ORC_ARMY_MAX - s->army[to]);
+        uint8_t reinforcement = max_reinf < s->reinf ? max_reinf : s->reinf;
+        if (reinforcement == 0) return ORC_LOGIC_ERROR; /* the reference would spin forever */
+        while (reinforcement > 0) {
+            uint8_t step = (int)reinforcement < cfg->min_unit_move ? reinforcement : (uint8_t)cfg->min_unit_move;
+            TRY(reinforcement_move(s, step, to));
+            reinforcement = (uint8_t)(reinforcement - step);
+        }
+    }
+    p->attack_from_army = s->army[p->land_from];
+    while (p->attack_from_army > 1) {
+        const uint8_t owner_before = s->owner[p->land_to];
+        TRY(attack_move(s, p->land_from, p->land_to, r));
+        int captured = s->owner[p->land_to] != owner_before; /* attackMove's return value */
+        p->attack_from_army = s->army[p->land_from];
+        if (captured && p->attack_from_army > 1) {
+            uint8_t max_move = (uint8_t)(p->attack_from_army - 1);
+            while (max_move > 0) {
+                uint8_t step = (int)max_move < cfg->min_unit_move ? max_move : (uint8_t)cfg->min_unit_move;
+                max_move = (uint8_t)(max_move - step);
+                TRY(attack_reinforcement_move(s, step));
+            }
+            break;
+        }
+    }
+    return ORC_OK;
+}
+
+/* GameHelper::PlayerMovement (game_helper.cpp:51-109): per owned component in discovery order — fortify-from = the
+ * land with no non-owned neighbour and the largest army (first wins), fortify-to = the land with most non-owned
+ * neighbours (first wins); components then std::sort'ed by fortify-from amount, descending.  libstdc++ sorts fewer
+ * than 17 elements by insertion sort (stable); more than 16 owned components cannot occur in practice. */
+typedef struct { uint64_t mask; int from, to; uint8_t from_amount, to_nb; } orc_lsm;
+
+static void lsm_flood(const orc_state* s, int land, uint64_t owned, orc_lsm* c)
+{
+    if (((1ULL << land) & owned & ~c->mask) > 0) {
+        c->mask |= 1ULL << land;
+        uint64_t att = ~owned & nb_mask(land);
+        if (att == 0) {
+            if (s->army[land] > c->from_amount) { c->from = land; c->from_amount = s->army[land]; }
+        } else {
+            uint8_t cnt = (uint8_t)popc(att);
+            if (cnt > c->to_nb) { c->to_nb = cnt; c->to = land; }
+        }
+        for (int i = 0; i < LAND[land].n; i++) lsm_flood(s, LAND[land].nb[i], owned, c);
+    }
+}
+
+static int player_movement(const orc_state* s, orc_lsm* out)
+{
+    uint64_t owned = s->ps[s->cur].owned, covered = 0;
+    int n = 0;
+    for (int i = 0; i < ORC_LANDS; i++)
+        if (((1ULL << i) & owned & ~covered) > 0) {
+            orc_lsm c = {0, ORC_NONE, ORC_NONE, 0, 0};
+            lsm_flood(s, i, owned, &c);
+            covered |= c.mask;
+            out[n++] = c;
+        }
+    for (int i = 1; i < n; i++) { /* stable insertion sort, descending by from_amount */
+        orc_lsm v = out[i];
+        int j = i;
+        while (j > 0 && v.from_amount > out[j - 1].from_amount) { out[j] = out[j - 1]; j--; }
+        out[j] = v;
+    }
+    return n;
+}
+
+/* ScriptPlayer::takeTurn (script_player.cpp:162-227) */
+int orc_script_take_turn(orc_script* p, orc_state* s, orc_rng* r, const orc_settings* cfg)
+{
+    const orc_player* ps = &s->ps[s->cur];
+    if (s->phase == ORC_SETUP) {
+        p->owned_attack_mask = ps->owned;
+        p->attack_mask = ps->attack;
+        script_update(p, s);
+        if (p->land_from == ORC_NONE) return ORC_LOGIC_ERROR;
+        TRY(setup_reinforcement_move(s, p->land_from));
+        const orc_player* eps = cenemy_ps(s);
+        uint64_t neutral = ALL_LANDS & ~ps->owned & ~eps->owned;
+        uint64_t nte = neutral & eps->attack & ~ps->attack;
+        if (nte == 0) nte = neutral & eps->attack;
+        uint64_t pick = popc(nte) > 0 ? orc_random_mask(r, nte) : orc_random_mask(r, neutral);
+        return setup_reinforcement_neutral_move(s, ctz(pick));
+    }
+    p->owned_attack_mask = ps->owned;
+    p->attack_mask = ps->attack;
+    play_cards(s);
+    while (p->attack_mask > 0 || s->reinf > 0) {
+        script_update(p, s);
+        TRY(script_attack_land(p, s, r, cfg));
+        p->owned_attack_mask = ps->owned_army;
+        p->attack_mask = ps->attack_army;
+    }
+    /* fortify (script_player.cpp:138-160) */
+    if (popc(ps->owned_army) > 0) {
+        orc_lsm comps[ORC_LANDS];
+        int n = player_movement(s, comps);
+        if (n > 0 && comps[0].from_amount > 0 && comps[0].to != ORC_NONE) {
+            uint8_t amount = (uint8_t)(s->army[comps[0].from] - 1);
+            uint8_t max_amount = (uint8_t)(ORC_ARMY_MAX - s->army[comps[0].to]);
+            amount = amount < max_amount ? amount : max_amount;
+            TRY(fortify_move(s, amount, comps[0].from, comps[0].to));
+        }
+    }
+    next_player_game_turn(s);
+    return ORC_OK;
+}
+
+/* RandomPlayer::pickRandomMove == Utility::randomMask with a throw on the empty set (random_player.cpp:3-20) */
+static int pick_random_move(orc_rng* r, uint64_t moves, uint64_t* out)
+{
+    if (popc(moves) == 0) return ORC_INVALID_ARGUMENT;
+    *out = orc_random_mask(r, moves);
+    return ORC_OK;
+}
+
+/* RandomPlayer::takeTurn (random_player.cpp:22-111) */
+int orc_random_take_turn(orc_state* s, int me, orc_rng* r, const orc_settings* cfg)
+{
+    while (orc_game_status(s, cfg) == ORC_NOT_ENDED && s->cur == me) {
+        const orc_player* ps = &s->ps[s->cur];
+        const orc_player* eps = cenemy_ps(s);
+        uint64_t mv;
+        if (s->phase == ORC_SETUP) {
+            TRY(pick_random_move(r, ps->owned, &mv));
+            TRY(setup_reinforcement_move(s, ctz(mv)));
+        } else if (s->phase == ORC_SETUP_NEUTRAL) {
+            TRY(pick_random_move(r, ALL_LANDS & ~ps->owned & ~eps->owned, &mv));
+            TRY(setup_reinforcement_neutral_move(s, ctz(mv)));
+        } else if (s->phase == ORC_REINFORCEMENT) {
+            play_cards(s);
+            TRY(pick_random_move(r, ps->owned & ~ps->owned_full, &mv));
+            TRY(reinforcement_move(s, 1, ctz(mv)));
+        } else if (s->phase == ORC_ATTACK) {
+            TRY(pick_random_move(r, ps->attack_army | SKIP_MASK, &mv));
+            if ((SKIP_MASK & mv) > 0) { TRY(goto_fortify(s)); }
+            else {
+                int to = ctz(mv);
+                uint64_t from;
+                TRY(pick_random_move(r, nb_mask(to) & ps->owned_army, &from));
+                TRY(attack_move(s, ctz(from), to, r));
+            }
+        } else if (s->phase == ORC_ATTACK_MOBILIZATION) {
+            if (orc_rng_float(r) > 0.5f) {
+                int v = (int)s->army[s->mob_from] - 1;
+                uint8_t amount = (uint8_t)(v < cfg->min_unit_move ? v : cfg->min_unit_move);
+                TRY(attack_reinforcement_move(s, amount));
+            } else { TRY(goto_attack(s)); }
+        } else if (s->phase == ORC_FORTIFY) {
+            TRY(pick_random_move(r, (ps->owned & ~ps->owned_full) | SKIP_MASK, &mv));
+            if (mv != SKIP_MASK) {
+                int to = ctz(mv);
+                orc_lsm comps[ORC_LANDS];
+                int n = player_movement(s, comps);
+                for (int i = 0; i < n; i++)
+                    if ((comps[i].mask & mv) > 0) {
+                        uint64_t with_army = comps[i].mask & ~mv & ps->owned_army;
+                        if (with_army > 0) {
+                            uint64_t fm;
+                            TRY(pick_random_move(r, with_army, &fm));
+                            int from = ctz(fm);
+                            uint8_t amount = (uint8_t)(s->army[from] - 1);
+                            uint8_t max_amount = (uint8_t)(ORC_ARMY_MAX - s->army[to]);
+                            amount = max_amount < amount ? max_amount : amount;
+                            if (amount == 0) return ORC_LOGIC_ERROR; /* rInt() % 0 in the reference */
+                            uint64_t ra = (uint64_t)(orc_rng_int(r) % amount);
+                            TRY(fortify_move(s, (uint8_t)ra, from, to));
+                        }
+                        break;
+                    }
+            }
+            next_player_game_turn(s);
+        }
+    }
+    return ORC_OK;
+}
+
+/* AlphaZeroPlayer::takeTurn (alphazero_player.cpp:3-21) at one search thread */
+static int az_take_turn(orc_mcts* m, orc_state* s, int me, orc_rng* r, const orc_settings* cfg, orc_eval_fn eval, void* ctx)
+{
+    orc_mcts_trim(m);
+    while (orc_game_status(s, cfg) == ORC_NOT_ENDED && s->cur == me) {
+        TRY(orc_mcts_simulate(m, s, r, eval, ctx));
+        float pi[ORC_MOVES];
+        TRY(orc_mcts_policy(m, s, pi));
+        int li = orc_pick_highest(pi);
+        TRY(orc_make_move(s, li, r, cfg));
+    }
+    return ORC_OK;
+}
+
+/* One thread of GameGroup::playGames (game.cpp:238-254) = Game::playGames(1) repeated `games` times with
+ * alternating starts and mirrored pairs (Game::newGame, game.cpp:170-191).  kinds: 0 = AlphaZero (eval), 1 = Script,
+ * 2 = Random.  One RNG stream for everything (the reference's global engine).  Optional per-game outputs. */
+int orc_play_games(const orc_settings* cfg, int kind0, int kind1, int games, int mirror, uint32_t seed,
+                   orc_eval_fn eval, void* ctx, orc_results* res, int8_t* status_out, uint8_t* finals160,
+                   uint16_t* rounds_out)
+{
+    orc_rng r;
+    orc_rng_seed(&r, seed);
+    orc_script sp[2];
+    orc_mcts* mc[2] = {NULL, NULL};
+    const int kind[2] = {kind0, kind1};
+    for (int p = 0; p < 2; p++) {
+        orc_script_init(&sp[p]);
+        if (kind[p] == 0) mc[p] = orc_mcts_create(cfg);
+    }
+    memset(res, 0, sizeof *res);
+    orc_state s, prev_start;
+    orc_state_blank(&prev_start);
+    int player_start = 0, rc = ORC_OK;
+    for (int gi = 0; gi < games && rc == ORC_OK; gi++) {
+        if (mirror && player_start != 0) {
+            s = prev_start;
+            orc_invert_players(&s);
+            s.cur = (int8_t)player_start;
+        } else {
+            orc_new_game(&s, &r);
+            s.cur = (int8_t)player_start;
+            prev_start = s;
+        }
+        for (int p = 0; p < 2; p++)
+            if (mc[p]) orc_mcts_clear(mc[p]); /* AlphaZeroPlayer::newGame */
+        int gs = ORC_NOT_ENDED;
+        while (gs == ORC_NOT_ENDED && rc == ORC_OK) { /* Game::gameLoop / playTurn (game.cpp:101-133) */
+            int cur = s.cur;
+            int setup = s.phase == ORC_SETUP;
+            if (kind[cur] == 1) rc = orc_script_take_turn(&sp[cur], &s, &r, cfg);
+            else if (kind[cur] == 2) rc = orc_random_take_turn(&s, cur, &r, cfg);
+            else rc = az_take_turn(mc[cur], &s, cur, &r, cfg, eval, ctx);
+            if (rc) break;
+            gs = setup ? ORC_NOT_ENDED : orc_game_status(&s, cfg);
+            if (cur == s.cur && gs == ORC_NOT_ENDED) { rc = ORC_LOGIC_ERROR; break; } /* "Turn was not incremented" */
+        }
+        if (rc) break;
+        res->count++;
+        if (gs == ORC_DRAW) res->draw++;
+        for (int p = 0; p < 2; p++)
+            if (gs == p) { res->win[p]++; if (player_start == p) res->win_started[p]++; }
+        if (status_out) status_out[gi] = (int8_t)gs;
+        if (finals160) orc_state_pack(&s, finals160 + (size_t)gi * 160);
+        if (rounds_out) rounds_out[gi] = s.round;
+        player_start = (player_start + 1) % 2;
+    }
+    for (int p = 0; p < 2; p++)
+        if (mc[p]) orc_mcts_destroy(mc[p]);
+    res->rng_state = r.x;
+    return rc;
+}

@@ -144,6 +144,25 @@ int orc_selfplay_game(const orc_settings* cfg, uint32_t seed, orc_eval_fn eval, 
                       uint8_t* rec265, int cap, int* status, int* rounds, uint8_t* moves_out, int max_decisions,
                       uint64_t* sims_out, uint64_t* evals_out);
 
+/* ---- opponents and the host game driver, pinned against oracle/_ref ---- */
+typedef struct {
+    uint8_t order[6];               /* attackLandSetPriority as a permutation of {ASIA,NA,SA,EU,AF,AU} */
+    uint8_t not_owned[6], not_owned_attack[6];
+    int attacking_set;              /* members of ScriptPlayer persist across turns AND games */
+    int land_to, land_from;
+    uint8_t attack_from_army;
+    uint64_t owned_attack_mask, attack_mask;
+} orc_script;
+typedef struct { int count, draw, win[2], win_started[2]; uint32_t rng_state; } orc_results;
+void orc_script_init(orc_script* p);
+int orc_script_take_turn(orc_script* p, orc_state* s, orc_rng* r, const orc_settings* cfg);
+int orc_random_take_turn(orc_state* s, int me, orc_rng* r, const orc_settings* cfg);
+int orc_landset_lands(int set, uint8_t* out12);
+/* kinds: 0 AlphaZero (needs eval), 1 ScriptPlayer, 2 RandomPlayer */
+int orc_play_games(const orc_settings* cfg, int kind0, int kind1, int games, int mirror, uint32_t seed,
+                   orc_eval_fn eval, void* ctx, orc_results* res, int8_t* status_out, uint8_t* finals160,
+                   uint16_t* rounds_out);
+
 /* bench.py cpu_baseline: `threads` games in parallel, `decisions` decisions each, fp32 CPU net */
 int orc_bench_selfplay(const orc_settings* cfg, const orc_net* net, uint32_t base_seed, int threads, int decisions,
                        uint64_t* sims, uint64_t* evals, double* seconds);

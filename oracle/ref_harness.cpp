@@ -25,6 +25,8 @@
 #include <cstdio>
 
 #include "risk_game/player/alpha_zero/alphazero_moves.h"
+#include "risk_game/player/script/script_player.h"
+#include "risk_game/player/random/random_player.h"
 
 static_assert(sizeof(Data) == 160, "reference Data layout changed");
 static_assert(sizeof(NNInputData) == 88, "reference NNInputData layout changed");
@@ -226,6 +228,50 @@ int ref_play_random_game(uint32_t seed, int cap, uint8_t* states160, uint64_t* m
     }
     *status = st;
     store_state(s, final160);
+    return n;
+}
+
+
+// ---- opponents + host game driver (player/script, player/random, game/game.cpp): one thread of GameGroup::playGames ----
+// kinds: 1 = ScriptPlayer, 2 = RandomPlayer.  results6 = {count, draw, win0, winStarted0, win1, winStarted1}.
+int ref_play_games(int kind0, int kind1, int games, int mirror, uint32_t seed, int* results6, int8_t* status,
+                   uint8_t* finals160, uint16_t* rounds, uint32_t* rng_state)
+{
+    SETTINGS.MIRROR_GAMES = mirror != 0;
+    ref_seed(seed);
+    auto mk = [](int kind) -> std::shared_ptr<Player> {
+        if (kind == 1) return std::shared_ptr<Player>(new ScriptPlayer());
+        return std::shared_ptr<Player>(new RandomPlayer());
+    };
+    Game game;
+    game.addPlayer(mk(kind0));
+    game.addPlayer(mk(kind1));
+    GameResults total;
+    try {
+        for (int i = 0; i < games; i++) {
+            GameResults gr = game.playGames(1);
+            total.add(gr);
+            if (status) status[i] = (int8_t)game.state.gameStatus();
+            if (finals160) store_state(game.state, finals160 + (size_t)i * sizeof(Data));
+            if (rounds) rounds[i] = game.state.getRound();
+        }
+    } catch (const std::exception& e) {
+        std::snprintf(g_err, sizeof g_err, "exception: %s", e.what());
+        return 1;
+    }
+    results6[0] = total.count; results6[1] = total.draw;
+    results6[2] = total.players[0].win; results6[3] = total.players[0].winAndStartedGame;
+    results6[4] = total.players[1].win; results6[5] = total.players[1].winAndStartedGame;
+    if (rng_state) *rng_state = ref_rng_state();
+    return 0;
+}
+
+int ref_landset_lands(int set, uint8_t* out12)
+{
+    const LandSet* sets[6] = {&LandSet::ASIA, &LandSet::NORTH_AMERICA, &LandSet::SOUTH_AMERICA, &LandSet::EUROPE,
+                              &LandSet::AFRICA, &LandSet::AUSTRALIA};
+    int n = (int)sets[set]->lands.size();
+    for (int i = 0; i < n; i++) out12[i] = Utility::li2i(sets[set]->lands[i]->landIndex);
     return n;
 }
 

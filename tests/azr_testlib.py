@@ -40,6 +40,14 @@ class OrcState(C.Structure):
                 ("attacks", C.c_uint8), ("drawn", C.c_uint16)]
 
 
+class OrcResults(C.Structure):
+    _fields_ = [("count", C.c_int), ("draw", C.c_int), ("win", C.c_int * 2), ("win_started", C.c_int * 2),
+                ("rng_state", C.c_uint32)]
+
+    def as_tuple(self):
+        return (self.count, self.draw, self.win[0], self.win_started[0], self.win[1], self.win_started[1])
+
+
 class OrcRng(C.Structure):
     _fields_ = [("x", C.c_uint32)]
 
@@ -94,6 +102,8 @@ def oracle():
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_play_random_game.argtypes = [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]
+        L.orc_play_games.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_net_forward_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_net_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _oracle = L
@@ -129,6 +139,8 @@ def ref():
         L.ref_normalize.argtypes = [C.c_void_p, C.c_uint64]
         L.ref_update_values.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.ref_invert_players.argtypes = [C.c_void_p]
+        L.ref_play_games.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
         L.ref_play_random_game.argtypes = [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p]
         _ref = L
@@ -246,3 +258,29 @@ def bn_offsets(blocks):
 
 def bias_offsets(blocks):
     return [(off, n) for name, off, n in _layout(blocks)[0] if name.endswith("_b")]
+
+
+def orc_play_games(kind0, kind1, games, mirror, seed, cfg=None, eval_fn=None):
+    """one slot ("thread") of GameGroup::playGames in the oracle; returns (results tuple, status, rounds, finals, rng)"""
+    L = oracle()
+    cfg = cfg or default_settings()
+    res = OrcResults()
+    st = np.zeros(games, np.int8)
+    fin = np.zeros((games, 160), np.uint8)
+    rd = np.zeros(games, np.uint16)
+    rc = L.orc_play_games(C.byref(cfg), kind0, kind1, games, int(mirror), seed, eval_fn, None, C.byref(res), ptr(st),
+                          ptr(fin), ptr(rd))
+    assert rc == 0, rc
+    return res.as_tuple(), st, rd, fin, res.rng_state
+
+
+def ref_play_games(kind0, kind1, games, mirror, seed):
+    L = ref()
+    r6 = (C.c_int * 6)()
+    st = np.zeros(games, np.int8)
+    fin = np.zeros((games, 160), np.uint8)
+    rd = np.zeros(games, np.uint16)
+    rs = C.c_uint32()
+    rc = L.ref_play_games(kind0, kind1, games, int(mirror), seed, r6, ptr(st), ptr(fin), ptr(rd), C.byref(rs))
+    assert rc == 0, L.ref_last_error()
+    return tuple(r6), st, rd, fin, rs.value

@@ -17,6 +17,7 @@ deterministic.  What each file pins:
   encode.npz        a12     NNInputData 88-byte images of sampled states
   normalize.npz     a15     NNOutputData::normalize on random priors x legal masks
   update_values.npz a24     z back-fill per record
+  players_games.npz f-1,f-3 ScriptPlayer / RandomPlayer / Game (mirrored pairs, alternating starts): results, final states
 """
 import os
 import sys
@@ -135,6 +136,19 @@ def main():
         zs[f"z_{gs}"] = z
     np.savez_compressed(os.path.join(HERE, "update_values.npz"), players=pl, z_p0=zs["z_0"], z_p1=zs["z_1"],
                         z_draw=zs["z_-2"])
+    # ---- opponents + host game driver (ScriptPlayer / RandomPlayer / Game mirrored pairs): f-1, f-3
+    rows = []
+    for (k0, k1) in ((1, 2), (2, 1), (1, 1), (2, 2)):
+        for mirror in (1, 0):
+            for seed in (1, 2, 3):
+                r6, st, rd, fin, rs = T.ref_play_games(k0, k1, 6, mirror, seed)
+                fin = fin.copy(); fin[:, ~fm] = 0
+                rows.append((k0, k1, mirror, seed, r6, st, rd, fin, rs))
+    np.savez_compressed(os.path.join(HERE, "players_games.npz"),
+                        kinds=np.array([[r[0], r[1]] for r in rows], np.int8), mirror=np.array([r[2] for r in rows], np.int8),
+                        seeds=np.array([r[3] for r in rows], np.uint32), results=np.array([r[4] for r in rows], np.int32),
+                        status=np.stack([r[5] for r in rows]), rounds=np.stack([r[6] for r in rows]),
+                        finals=np.stack([r[7] for r in rows]), rng_state=np.array([r[8] for r in rows], np.uint32))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1,0 +1,85 @@
+"""GPU parity, SURVEY §8 f-1 / f-3 and BASELINE configs[0]: the device arena (GameGroup::playGames with
+AlphaZeroPlayer / ScriptPlayer / RandomPlayer, mirrored pairs) against the oracle, which is pinned bit-exactly to the
+real reference for ScriptPlayer, RandomPlayer and the Game driver (tests/test_oracle_vs_ref.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import azr_testlib as T
+from gpu_common import pkg
+
+pytestmark = pytest.mark.gpu
+FM = T.data_field_mask()
+
+
+def run_arena(eng, k0, k1, total, cap, mirror, base):
+    eng.arena_start(k0, k1, total, per_slot_cap=cap, mirror=mirror, base_seed=base)
+    for _ in range(2000):
+        if eng.arena_run(64):
+            break
+    else:
+        raise AssertionError("arena did not finish")
+    return eng.arena_results(), eng.arena_log()
+
+
+@pytest.mark.parametrize("kinds", [(1, 2), (2, 1), (1, 1), (2, 2)])
+@pytest.mark.parametrize("mirror", [True, False])
+def test_script_and_random_players_arena_bit_exact(orc, kinds, mirror):
+    P = pkg()
+    G, per_slot, base = 96, 6, 555
+    eng = P.Engine(G, blocks=1, sims=1, dtype=P.NET_F32, node_capacity=64)
+    res, (n, st, rd, fin) = run_arena(eng, kinds[0], kinds[1], 10 ** 6, per_slot, mirror, base)
+    assert (n == per_slot).all() and eng.counters()["errors"] == 0
+    tot = np.zeros(6, np.int64)
+    for g in range(G):
+        r6, ost, ord_, ofin, _ = T.orc_play_games(kinds[0], kinds[1], per_slot, mirror, base + g)
+        assert (st[g, :per_slot] == ost).all(), g
+        assert (rd[g, :per_slot] == ord_).all(), g
+        assert (fin[g, :per_slot][:, FM] == ofin[:, FM]).all(), g
+        tot += np.array(r6)
+    assert [res["count"], res["draw"], res["win"][0], res["win_and_started"][0], res["win"][1],
+            res["win_and_started"][1]] == list(tot)
+    eng.close()
+
+
+def test_counter_semantics_pairs_and_quota():
+    """Counter::hasNext(2) (game.cpp:14-26): games are taken in pairs from a shared counter; an odd quota leaves the
+    last game unplayed"""
+    P = pkg()
+    eng = P.Engine(8, blocks=1, sims=1, dtype=P.NET_F32, node_capacity=64)
+    res, (n, _, _, _) = run_arena(eng, P.PLAYER_SCRIPT, P.PLAYER_RANDOM, 21, 0, True, 1)
+    assert res["count"] == 20 and n.sum() == 20 and (n % 2 == 0).all()
+    assert res["draw"] + res["win"][0] + res["win"][1] == 20
+    eng.close()
+
+
+@pytest.mark.parametrize("az_first", [True, False])
+def test_alphazero_vs_script_config0_bit_exact(orc, az_first):
+    """BASELINE configs[0] shape: `-m play --mcts=16` AlphaZero vs ScriptPlayer.  Oracle side: AlphaZeroPlayer::takeTurn
+    (extra trim per turn, argmax) with the DEVICE net called back for every evaluation."""
+    P = pkg()
+    G, per_slot, S, B, base = 6, 2, 16, 1, 4100
+    eng = P.Engine(G, blocks=B, sims=S, dtype=P.NET_F32)
+    eng.set_weights(T.make_net_flat(B, seed=21, perturb_bn=True))
+    k = (P.PLAYER_ALPHAZERO, P.PLAYER_SCRIPT) if az_first else (P.PLAYER_SCRIPT, P.PLAYER_ALPHAZERO)
+    res, (n, st, rd, fin) = run_arena(eng, k[0], k[1], 10 ** 6, per_slot, True, base)
+    assert (n == per_slot).all() and eng.counters()["errors"] == 0
+
+    @T.EVAL_FN
+    def hip_eval(ctx, in88, pi, v):
+        x = np.ctypeslib.as_array(in88, shape=(88,)).copy()[None]
+        p, vv = eng.predict(x)
+        C.memmove(pi, p.ctypes.data, 43 * 4)
+        v[0] = float(vv[0])
+
+    cfg = T.default_settings(mcts_simulations=S)
+    tot = np.zeros(6, np.int64)
+    for g in range(G):
+        r6, ost, ord_, ofin, _ = T.orc_play_games(k[0], k[1], per_slot, True, base + g, cfg=cfg, eval_fn=hip_eval)
+        assert (st[g, :per_slot] == ost).all(), (g, st[g], ost)
+        assert (rd[g, :per_slot] == ord_).all(), g
+        assert (fin[g, :per_slot][:, FM] == ofin[:, FM]).all(), g
+        tot += np.array(r6)
+    assert res["count"] == tot[0] and res["win"][0] == tot[2] and res["win"][1] == tot[4]
+    eng.close()

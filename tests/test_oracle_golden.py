@@ -140,3 +140,15 @@ def test_planes_follow_plane_indices(orc):
         assert (t[:, 3] == f[9]).all() and (t[:, 4] == f[0]).all() and (t[:, 5] == f[1]).all()
         assert (t[:, 6] == f[2]).all()
         assert np.array_equal(t[0, 7:13], f[3:9]) and t[:, 7:13].sum() == 42.0
+
+
+def test_players_and_game_driver(orc):
+    """ScriptPlayer, RandomPlayer and Game's mirrored pairs against the reference's results"""
+    g = load("players_games.npz")
+    for i in range(len(g["seeds"])):
+        k0, k1 = (int(x) for x in g["kinds"][i])
+        res, st, rd, fin, rs = T.orc_play_games(k0, k1, 6, int(g["mirror"][i]), int(g["seeds"][i]))
+        assert res == tuple(int(x) for x in g["results"][i]), i
+        assert (st == g["status"][i]).all() and (rd == g["rounds"][i]).all()
+        assert (fin[:, FM] == g["finals"][i][:, FM]).all()
+        assert rs == int(g["rng_state"][i])

@@ -70,3 +70,15 @@ def test_invert_players(orc):
         b = np.zeros(160, np.uint8)
         orc.orc_state_pack(C.byref(s), T.ptr(b))
         assert (a[FM] == b[FM]).all()
+
+
+@pytest.mark.parametrize("kinds", [(1, 2), (2, 1), (1, 1), (2, 2)])
+def test_players_and_game_driver_bit_exact(orc, kinds):
+    """ScriptPlayer / RandomPlayer / Game::playGames (mirrored pairs, alternating starts) against the real reference:
+    results, every final state, round counts and the RNG stream position"""
+    for mirror in (1, 0):
+        for seed in range(100, 130):
+            a = T.ref_play_games(kinds[0], kinds[1], 8, mirror, seed)
+            b = T.orc_play_games(kinds[0], kinds[1], 8, mirror, seed)
+            assert a[0] == b[0] and (a[1] == b[1]).all() and (a[2] == b[2]).all()
+            assert (a[3][:, FM] == b[3][:, FM]).all() and a[4] == b[4]
