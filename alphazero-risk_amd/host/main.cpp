@@ -1,6 +1,7 @@
 // AlphaZero_Risk_hip — CLI of the MI355X-native build; flags and modes as src/alphazero_risk.cpp:160-199 /
 // src/settings.h:91-137 (`-m learn` = `-m train`).
 #include <cstdio>
+#include <thread>
 
 #include "azr_host.hpp"
 
@@ -16,18 +17,19 @@ static void executeTrain()
     trainer.train(generateGroup, generateGroup);
 }
 
-// `-m play` with both sides "az": AlphaZeroPlayerGroup vs itself through the batched Player seam.
-// ScriptPlayer / RandomPlayer opponents are SURVEY §8(f-3) "next" rows.
-static void executePlay()
+// `-m play` (src/alphazero_risk.cpp:4-47): GameGroup::playGames(group1, group2, COMPARE_GAMES) on the device arena.
+// az vs sp / rp (either side) and sp / rp among themselves run through azr_arena_*; az vs az goes through the batched
+// Player seam (AlphaZeroPlayerGroup::takeTurns) with one shared net.
+static int playerKind(const std::string& p)
 {
-    if (SETTINGS.PLAYER_1 != "az" || SETTINGS.PLAYER_2 != "az") {
-        printf("This round builds the AlphaZero player only (--p1=az --p2=az); ScriptPlayer/RandomPlayer are SURVEY §8f-3.\n");
-        return;
-    }
-    auto cluster = std::make_shared<AlphaZeroCluster>();
-    cluster->initGpus(SETTINGS.NUMBER_OF_GPUS);
-    auto group = cluster->initPlayerGroup("az1", SETTINGS.GRAPH_DEF_PB_1);
-    group->loadCheckpoint(SETTINGS.CHECKPOINT_1);
+    if (p == "az") return AZR_PLAYER_ALPHAZERO;
+    if (p == "sp") return AZR_PLAYER_SCRIPT;
+    if (p == "rp") return AZR_PLAYER_RANDOM;
+    throw std::invalid_argument("unknown player '" + p + "' (az/sp/rp)");
+}
+
+static void executePlayAzVsAz(std::shared_ptr<AlphaZeroNNGroup> group)
+{
     AlphaZeroPlayerGroup players(group);
     Engine& e = *group->getNN(0)->engine;
     const int G = e.games;
@@ -58,6 +60,46 @@ static void executePlay()
         fflush(stdout);
     }
     printf("\nGames: %d\nDraws:%d\nPlayer 1:%d\nPlayer 2:%d\n", count, draws, wins[0], wins[1]);
+}
+
+static void executePlay()
+{
+    const int k1 = playerKind(SETTINGS.PLAYER_1), k2 = playerKind(SETTINGS.PLAYER_2);
+    auto cluster = std::make_shared<AlphaZeroCluster>();
+    cluster->initGpus(SETTINGS.NUMBER_OF_GPUS);
+    auto group = cluster->initPlayerGroup("az1", SETTINGS.GRAPH_DEF_PB_1);
+    if (k1 == AZR_PLAYER_ALPHAZERO) group->loadCheckpoint(SETTINGS.CHECKPOINT_1);
+    else if (k2 == AZR_PLAYER_ALPHAZERO) group->loadCheckpoint(SETTINGS.CHECKPOINT_2);
+    if (k1 == AZR_PLAYER_ALPHAZERO && k2 == AZR_PLAYER_ALPHAZERO) { executePlayAzVsAz(group); return; }
+    // one host thread per GPU, the game quota split over the GPUs (the reference shares one Counter)
+    const int P = (int)group->size();
+    std::vector<azr_game_results> res(P);
+    std::vector<std::thread> threads;
+    printf("Playing games %d\n", SETTINGS.COMPARE_GAMES);
+    for (int i = 0; i < P; i++)
+        threads.emplace_back([&, i]() {
+            Engine& e = *group->getNN(i)->engine;
+            const int share = SETTINGS.COMPARE_GAMES / P + (i < SETTINGS.COMPARE_GAMES % P ? 1 : 0);
+            e.check(azr_arena_start(e.h, k1, k2, share, 0, SETTINGS.MIRROR_GAMES, SETTINGS.BASE_SEED + (uint32_t)i * (1u << 24)),
+                    "arena_start");
+            int fin = 0;
+            while (!fin) {
+                e.check(azr_arena_run(e.h, 4 * (SETTINGS.MCTS_SIMULATIONS + 2), &fin), "arena_run");
+                e.check(azr_arena_results(e.h, &res[i]), "arena_results");
+                if (i == 0) {
+                    printf("\r%d/%d [Draw/P1,P2]: %d, %d/%d, %d/%d", res[i].count, share, res[i].draw, res[i].win[0],
+                           res[i].win_and_started[0], res[i].win[1], res[i].win_and_started[1]);
+                    fflush(stdout);
+                }
+            }
+        });
+    for (auto& t : threads) t.join();
+    azr_game_results gr{};
+    for (auto& r : res) {
+        gr.count += r.count; gr.draw += r.draw;
+        for (int p = 0; p < 2; p++) { gr.win[p] += r.win[p]; gr.win_and_started[p] += r.win_and_started[p]; }
+    }
+    printf("\nGames: %d\nDraws:%d\nPlayer 1:%d\nPlayer 2:%d\n", gr.count, gr.draw, gr.win[0], gr.win[1]);
 }
 
 int main(int argc, char* argv[])

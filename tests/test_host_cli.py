@@ -70,3 +70,25 @@ def test_play_mode_az_vs_az(exe, tmp_path):
     assert tail[0] == "Games: 8"
     d, p1, p2 = (int(t.split(":")[1]) for t in tail[1:])
     assert d + p1 + p2 == 8
+
+
+@pytest.mark.gpu
+def test_play_mode_config0_az_vs_script(exe, tmp_path):
+    """BASELINE configs[0]: `-m play --mcts=16 --cg=N`, AlphaZero (p1, default) vs ScriptPlayer (p2, default)"""
+    r = subprocess.run([exe, "-m", "play", "--mcts=16", "--cg=12", "--gpu-games=4", "--blocks=1"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    tail = r.stdout.strip().split("\n")[-4:]
+    assert tail[0] == "Games: 12"
+    d, p1, p2 = (int(t.split(":")[1]) for t in tail[1:])
+    assert d + p1 + p2 == 12
+
+
+@pytest.mark.gpu
+def test_play_mode_script_vs_random(exe, tmp_path):
+    r = subprocess.run([exe, "-m", "play", "--p1=sp", "--p2=rp", "--cg=40", "--gpu-games=8", "--blocks=1"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr
+    tail = r.stdout.strip().split("\n")[-4:]
+    d, p1, p2 = (int(t.split(":")[1]) for t in tail[1:])
+    assert tail[0] == "Games: 40" and d + p1 + p2 == 40 and p1 > p2   # the scripted player beats the random one
