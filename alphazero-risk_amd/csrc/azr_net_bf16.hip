@@ -118,6 +118,18 @@ constexpr size_t KBYTES = KSTRIDE * 16;  // bytes per k-step of packed weights (
 // ring depth in taps (8 k-steps each)
 template <int NB, int NT> struct RingTaps { static constexpr int value = (NB == 1) ? 2 : 1; };
 
+// Operand orientation.  Swapped (1-board tile): weights are the MFMA "A" operand, so D = [channel][cell] and the
+// epilogue stores 4 consecutive channels per lane (8-byte LDS ops, 4x fewer).  The swapped epilogue needs 16 VGPRs of
+// BN constants instead of 4, which the 3-board tile (already at the 256-VGPR limit) cannot afford: it keeps D = [cell][channel].
+template <int MT> struct Swap { static constexpr bool value = MT <= 3; };
+__device__ __forceinline__ float bn_x(float v) { return v; }
+__device__ __forceinline__ float bn_x(const float4& v) { return v.x; }
+__device__ __forceinline__ float4 bn_4(float v) { return float4{v, v, v, v}; }
+__device__ __forceinline__ float4 bn_4(const float4& v) { return v; }
+template <bool SWAP> struct BnConst;                                  // folded-BN constants a lane needs per column tile
+template <> struct BnConst<true> { typedef float4 type; };           // 4 consecutive channels
+template <> struct BnConst<false> { typedef float type; };           // 1 channel
+
 // one tap = 8 k-steps against ring slots SB .. SB+7.  `wb` is the wave-UNIFORM byte pointer to the current
 // k-step's 16-KiB fragment block (advanced with scalar adds); `loff` is this lane's byte offset inside a block.
 template <int MT, int NT, int RT, int SB>
@@ -144,8 +156,14 @@ __device__ __forceinline__ void conv_tap(const uint8_t* IN, int tap, const char*
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int nt = 0; nt < NT; nt++)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[cur][mt]),
-                                                                      __builtin_bit_cast(bf16x8, bq[SB + ks][nt]), acc[mt][nt], 0, 0, 0);
+                if constexpr (Swap<MT>::value)
+                    // weights as the MFMA "A" operand, activations as "B": D[channel][cell], so a lane ends up with 4
+                    // CONSECUTIVE CHANNELS of one board cell (row = 4*(lane>>4)+j, col = lane&15) -> 8-byte LDS stores
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[SB + ks][nt]),
+                                                                          __builtin_bit_cast(bf16x8, a[cur][mt]), acc[mt][nt], 0, 0, 0);
+                else
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[cur][mt]),
+                                                                          __builtin_bit_cast(bf16x8, bq[SB + ks][nt]), acc[mt][nt], 0, 0, 0);
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
             bq[SB + ks][nt] = *reinterpret_cast<const s16x8*>(wb + RT * 8 * KBYTES + loff + nt * 1024);
@@ -166,7 +184,8 @@ __device__ __forceinline__ void conv_tap(const uint8_t* IN, int tap, const char*
 template <int MT, int NT, int RT, int PAR>
 __device__ __forceinline__ void conv_tower_layer(const uint8_t* IN, const char* __restrict__& wb, uint32_t loff,
                                                  s16x8 (&bq)[RT * 8][NT], f32x4 (&acc)[MT][NT], const int (&rinfo)[MT], int g16,
-                                                 int zero_row)
+                                                 int zero_row, const float* __restrict__ fs, typename BnConst<Swap<MT>::value>::type (&sc)[NT],
+                                                 typename BnConst<Swap<MT>::value>::type (&sh)[NT])
 {
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
@@ -179,7 +198,22 @@ __device__ __forceinline__ void conv_tower_layer(const uint8_t* IN, const char* 
         aoff[mt] = tap_row(rinfo[mt], -1, -1, zero_row) * ROWB + g16;
         a[0][mt] = *reinterpret_cast<const s16x8*>(IN + aoff[mt]);
     }
+    // this layer's folded BN (4 consecutive channels per lane and tile) is requested one tap before the epilogue:
+    // early enough not to wait behind the weight ring, late enough not to hold 16 VGPRs through the layer
+    auto load_bn = [&]() {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            if constexpr (Swap<MT>::value) {
+                sc[nt] = *reinterpret_cast<const typename BnConst<Swap<MT>::value>::type*>(fs + nt * 16);
+                sh[nt] = *reinterpret_cast<const typename BnConst<Swap<MT>::value>::type*>(fs + NF + nt * 16);
+            } else {  // one channel per lane and tile
+                sc[nt] = fs[nt * 16];
+                sh[nt] = fs[NF + nt * 16];
+            }
+        }
+    };
     if constexpr (RT == 1) {
+        load_bn();  // (register allocation at the 256-VGPR limit of the 3-board tile is best with the early load)
         for (int tap = 0; tap < 9; tap++) conv_tap<MT, NT, 1, 0>(IN, tap, wb, loff, bq, acc, a, aoff, rinfo, g16, zero_row);
     } else {
         constexpr int S0 = PAR ? 8 : 0, S1 = PAR ? 0 : 8;
@@ -187,6 +221,7 @@ __device__ __forceinline__ void conv_tower_layer(const uint8_t* IN, const char* 
             conv_tap<MT, NT, 2, S0>(IN, tap, wb, loff, bq, acc, a, aoff, rinfo, g16, zero_row);
             conv_tap<MT, NT, 2, S1>(IN, tap + 1, wb, loff, bq, acc, a, aoff, rinfo, g16, zero_row);
         }
+        load_bn();
         conv_tap<MT, NT, 2, S0>(IN, 8, wb, loff, bq, acc, a, aoff, rinfo, g16, zero_row);
     }
 }
@@ -196,7 +231,8 @@ __global__ __launch_bounds__(1024 / NT, NT == 2 ? 2 : 1) void k_tower_bf16(const
                                                                            const uint16_t* __restrict__ stem_wp,
                                                                            const uint16_t* __restrict__ tower_wp,
                                                                            const float* __restrict__ fold, int blocks,
-                                                                           uint16_t* __restrict__ out)
+                                                                           uint16_t* __restrict__ out,
+                                                                           unsigned long long* __restrict__ diag)
 {
     using G = Geo<NB>;
     constexpr int ROWS = G::ROWS, MT = G::MT, THREADS = 1024 / NT, WCOLS = NT * 16;
@@ -207,6 +243,9 @@ __global__ __launch_bounds__(1024 / NT, NT == 2 ? 2 : 1) void k_tower_bf16(const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
     const int board0 = blockIdx.x * NB;
+    // clock diagnostic (azr_debug_tower_clock): shader-clock and 100 MHz real-time stamps around the whole tower of
+    // workgroup 0; `diag` is null in every product launch
+    if (diag && blockIdx.x == 0 && tid == 0) { diag[0] = __builtin_amdgcn_s_memtime(); diag[1] = __builtin_amdgcn_s_memrealtime(); }
 
     // ---- stage the NNInputData images, zero the zero rows and the stem feature image
     for (int i = tid; i < NB * 96; i += THREADS) {
@@ -267,74 +306,110 @@ __global__ __launch_bounds__(1024 / NT, NT == 2 ? 2 : 1) void k_tower_bf16(const
                 const s16x8 av = *reinterpret_cast<const s16x8*>(bufT + row * FROWB + (g & 1) * 16);
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, b[nt]), acc[mt][nt], 0, 0, 0);
+                    if constexpr (Swap<MT>::value)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[nt]), __builtin_bit_cast(bf16x8, av), acc[mt][nt], 0, 0, 0);
+                    else
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, b[nt]), acc[mt][nt], 0, 0, 0);
             }
         }
-        // conv_bn over the board row + ReLU -> bufX   (C/D layout: col = lane & 15, row = (lane >> 4)*4 + j)
-        float rsc[MT][4], rsh[MT][4];
+        if constexpr (Swap<MT>::value) {
+        // conv_bn over the board row + ReLU -> bufX.  D layout: col = lane & 15 = board cell, row = 4*(lane>>4)+j = channel
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
+        for (int mt = 0; mt < MT; mt++) {
+            const int r = mt * 16 + m;
+            if (r < ROWS) {
+                const int y = (r % 42) / 6;
+                const float sc = fold[y], sh = fold[7 + y];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int r = mt * 16 + g * 4 + j;
-                const int y = r < ROWS ? (r % 42) / 6 : 0;
-                rsc[mt][j] = fold[y];
-                rsh[mt][j] = fold[7 + y];
-            }
+                for (int nt = 0; nt < NT; nt++) {
+                    const int c0 = wave * WCOLS + nt * 16 + g * 4;
+                    uint16_t o4[4];
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int r = mt * 16 + g * 4 + j;
-                if (r < ROWS) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; nt++) {
-                        const int co = wave * WCOLS + nt * 16 + m;
-                        float v = fmaf(acc[mt][nt][j], rsc[mt][j], rsh[mt][j]);
-                        reinterpret_cast<uint16_t*>(bufX + r * ROWB)[co] = bf_rne(v > 0.0f ? v : 0.0f);
+                    for (int j = 0; j < 4; j++) {
+                        const float v = fmaf(acc[mt][nt][j], sc, sh);
+                        o4[j] = bf_rne(v > 0.0f ? v : 0.0f);
                     }
+                    *reinterpret_cast<uint2*>(bufX + r * ROWB + c0 * 2) = uint2{(uint32_t)o4[0] | ((uint32_t)o4[1] << 16), (uint32_t)o4[2] | ((uint32_t)o4[3] << 16)};
                 }
             }
+        }
+        } else {
+            // D layout: col = lane & 15 = channel, row = 4*(lane>>4)+j = board cell
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int r = mt * 16 + g * 4 + j;
+                    if (r < ROWS) {
+                        const int y = (r % 42) / 6;
+                        const float sc = fold[y], sh = fold[7 + y];
+#pragma unroll
+                        for (int nt = 0; nt < NT; nt++) {
+                            const float v = fmaf(acc[mt][nt][j], sc, sh);
+                            reinterpret_cast<uint16_t*>(bufX + r * ROWB)[wave * WCOLS + nt * 16 + m] = bf_rne(v > 0.0f ? v : 0.0f);
+                        }
+                    }
+                }
+        }
     }
     __syncthreads();
 
     // ---- residual tower: 2 conv layers per block, activations resident in LDS
     const int g16 = g * 16;
-    auto epilogue = [&](bool second, uint8_t* OUT, const float (&sc)[NT], const float (&sh)[NT]) {
+    typedef typename BnConst<Swap<MT>::value>::type bn_t;
+    auto epilogue = [&](bool second, uint8_t* OUT, const bn_t (&sc)[NT], const bn_t (&sh)[NT]) {
+        if constexpr (!Swap<MT>::value) {
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
+            for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int r = mt * 16 + g * 4 + j;
-                if (r < ROWS) {
+                for (int j = 0; j < 4; j++) {
+                    const int r = mt * 16 + g * 4 + j;
+                    if (r < ROWS) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; nt++) {
-                        const int co = wave * WCOLS + nt * 16 + m;
-                        uint16_t* o = reinterpret_cast<uint16_t*>(OUT + r * ROWB) + co;
-                        float v = fmaf(acc[mt][nt][j], sc[nt], sh[nt]);
-                        if (second) v += bf2f(*o);  // shortcut: OUT still holds the block's input at this element
-                        *o = bf_rne(v > 0.0f ? v : 0.0f);
+                        for (int nt = 0; nt < NT; nt++) {
+                            uint16_t* o = reinterpret_cast<uint16_t*>(OUT + r * ROWB) + wave * WCOLS + nt * 16 + m;
+                            float v = fmaf(acc[mt][nt][j], bn_x(sc[nt]), bn_x(sh[nt]));
+                            if (second) v += bf2f(*o);  // shortcut: OUT still holds the block's input at this element
+                            *o = bf_rne(v > 0.0f ? v : 0.0f);
+                        }
                     }
                 }
+            return;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const int r = mt * 16 + m;
+            if (r < ROWS) {
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    uint2* o = reinterpret_cast<uint2*>(OUT + r * ROWB + (wave * WCOLS + nt * 16 + g * 4) * 2);
+                    const float4 s4 = bn_4(sc[nt]), h4 = bn_4(sh[nt]);
+                    float v0 = fmaf(acc[mt][nt][0], s4.x, h4.x), v1 = fmaf(acc[mt][nt][1], s4.y, h4.y);
+                    float v2 = fmaf(acc[mt][nt][2], s4.z, h4.z), v3 = fmaf(acc[mt][nt][3], s4.w, h4.w);
+                    if (second) {  // shortcut: OUT still holds the block's input at these 4 channels of this cell
+                        const uint2 x = *o;
+                        v0 += bf2f((uint16_t)(x.x & 0xffffu)); v1 += bf2f((uint16_t)(x.x >> 16));
+                        v2 += bf2f((uint16_t)(x.y & 0xffffu)); v3 += bf2f((uint16_t)(x.y >> 16));
+                    }
+                    const uint32_t lo = (uint32_t)bf_rne(v0 > 0.0f ? v0 : 0.0f) | ((uint32_t)bf_rne(v1 > 0.0f ? v1 : 0.0f) << 16);
+                    const uint32_t hi = (uint32_t)bf_rne(v2 > 0.0f ? v2 : 0.0f) | ((uint32_t)bf_rne(v3 > 0.0f ? v3 : 0.0f) << 16);
+                    *o = uint2{lo, hi};
+                }
             }
+        }
     };
     for (int blk = 0; blk < blocks; blk++) {
-        // each layer's folded BN is requested before its taps so the epilogue never waits behind the weight ring
-        float sc[NT], sh[NT];
-        const float* fs = fold + 14 + (size_t)(2 * blk) * 2 * NF;
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) { sc[nt] = fs[wave * WCOLS + nt * 16 + m]; sh[nt] = fs[NF + wave * WCOLS + nt * 16 + m]; }
-        conv_tower_layer<MT, NT, RT, 0>(bufX, wb, loff, bq, acc, rinfo, g16, ROWS);
+        bn_t sc[NT], sh[NT];
+        const float* fs = fold + 14 + (size_t)(2 * blk) * 2 * NF + wave * WCOLS + (Swap<MT>::value ? g * 4 : m);
+        conv_tower_layer<MT, NT, RT, 0>(bufX, wb, loff, bq, acc, rinfo, g16, ROWS, fs, sc, sh);
         epilogue(false, bufT, sc, sh);
         __syncthreads();
-        fs += 2 * NF;
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) { sc[nt] = fs[wave * WCOLS + nt * 16 + m]; sh[nt] = fs[NF + wave * WCOLS + nt * 16 + m]; }
-        conv_tower_layer<MT, NT, RT, 1>(bufT, wb, loff, bq, acc, rinfo, g16, ROWS);
+        conv_tower_layer<MT, NT, RT, 1>(bufT, wb, loff, bq, acc, rinfo, g16, ROWS, fs + 2 * NF, sc, sh);
         epilogue(true, bufX, sc, sh);
         __syncthreads();
     }
 
+    if (diag && blockIdx.x == 0 && tid == 0) { diag[2] = __builtin_amdgcn_s_memtime(); diag[3] = __builtin_amdgcn_s_memrealtime(); }
     // ---- final activation -> HBM (bf16 [board][42][256]) for the heads kernel
     for (int i = tid; i < ROWS * 32; i += THREADS) {
         const int r = i >> 5, seg = i & 31;
@@ -349,6 +424,7 @@ struct Bf16Net {
     uint16_t* stem_wp = nullptr;
     uint16_t* tower_wp = nullptr;
     uint16_t* act = nullptr;  // [G][42][256] bf16 tower output
+    unsigned long long* diag = nullptr;  // set only by azr_debug_tower_clock
 };
 Bf16Net* bn(azr_engine* h) { return reinterpret_cast<Bf16Net*>(h->net.bf16ctx); }
 }  // namespace
@@ -434,7 +510,7 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
     const int NT = nt_env == 4 ? 4 : 2;
 #define LAUNCH_TOWER(NBV, NTV)                                                                                      \
     hipLaunchKernelGGL((k_tower_bf16<NBV, NTV>), dim3((n + NBV - 1) / NBV), dim3(1024 / NTV), Geo<NBV>::LDS_BYTES, \
-                       h->stream, d_in88, in_stride, n, x->stem_wp, x->tower_wp, fold, B, x->act)
+                       h->stream, d_in88, in_stride, n, x->stem_wp, x->tower_wp, fold, B, x->act, x->diag)
     if (n <= 256) { if (NT == 2) LAUNCH_TOWER(1, 2); else LAUNCH_TOWER(1, 4); }
     else if (n <= 512) { if (NT == 2) LAUNCH_TOWER(2, 2); else LAUNCH_TOWER(2, 4); }
     else { if (NT == 2) LAUNCH_TOWER(3, 2); else LAUNCH_TOWER(3, 4); }
@@ -445,4 +521,28 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
     return AZR_OK;
 }
 
+
 }  // namespace azr
+
+// Diagnostic (not part of the product path): sustained shader clock of the tower kernel under load = d(s_memtime) /
+// d(s_memrealtime) x 100 MHz around workgroup 0's whole tower, after `warm` back-to-back launches on leaf buffers.
+extern "C" int azr_debug_tower_clock(azr_engine* h, int n, int warm, double* ghz_out, double* tower_ms_out)
+{
+    if (!h || !h->net.bf16ctx || !h->weights_set) return AZR_E_STATE;
+    Bf16Net* x = bn(h);
+    unsigned long long* d = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d, 4 * sizeof(unsigned long long)));
+    for (int i = 0; i < warm; i++) net_bf16_forward(h, h->d.leaf_in, LEAF_STRIDE, n, h->d.net_pi, h->d.net_v);
+    x->diag = d;
+    int rc = net_bf16_forward(h, h->d.leaf_in, LEAF_STRIDE, n, h->d.net_pi, h->d.net_v);
+    x->diag = nullptr;
+    unsigned long long v[4] = {0, 0, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(v, d, sizeof v, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    hipFree(d);
+    if (rc) return rc;
+    const double cyc = (double)(v[2] - v[0]), rt = (double)(v[3] - v[1]);
+    if (ghz_out) *ghz_out = rt > 0 ? cyc / rt * 0.1 : 0.0;
+    if (tower_ms_out) *tower_ms_out = rt * 1e-5;  // 100 MHz ticks -> ms
+    return AZR_OK;
+}
