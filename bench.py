@@ -42,7 +42,7 @@ def cpu_baseline(blocks, sims, seconds_budget=25.0):
 
     orc = T.oracle()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(cores, 64))  # "cores" reported = threads actually used
+    threads = max(1, min(cores, 16))  # a 1-GPU box has a 16-core CPU share; "cores" reported = threads actually used
     flat = T.make_net_flat(blocks)
     net = T.OrcNet(blocks, flat.ctypes.data_as(T.f32p))
     cfg = T.default_settings(mcts_simulations=sims)
@@ -84,11 +84,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the only path (no CPU fallback)")
+    # backend "nccl" IS RCCL on ROCm.  AZR_BENCH_BACKEND=gloo is a rehearsal switch for boxes with fewer GPUs than
+    # ranks (ranks then share GPUs and the record gather runs on host tensors).
+    backend = os.environ.get("AZR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     pkg = importlib.import_module("alphazero-risk_amd")
     from importlib import import_module
@@ -113,17 +122,17 @@ def main():
     eng.selfplay_run(a.steps)          # EXACTLY K passes (synchronises at the end)
     ptr, nrec = eng.samples_device_view()
     recs = shard.device_records_to_torch(ptr, nrec, dev)
-    allrecs = shard.gather_records(recs, dist if world > 1 else None)   # the path's one exchange step
+    allrecs = shard.gather_records(recs.to(cdev), dist if world > 1 else None)   # the path's one exchange step
     barrier()
     dt = time.perf_counter() - t0
     c1 = eng.counters()
     prof = eng.profile_last_run()
 
     delta = {k: c1[k] - c0[k] for k in c1}
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     tot = torch.tensor([delta["simulations"], delta["evaluations"], delta["levels"], delta["decisions"],
                         delta["games_finished"], delta["samples"], delta["errors"], delta["nodes_dropped"]],
-                       dtype=torch.int64, device=dev)
+                       dtype=torch.int64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
