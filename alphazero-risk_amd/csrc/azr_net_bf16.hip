@@ -14,7 +14,8 @@
 //   * Epilogue per layer in registers: folded BN (fp32 scale/shift per channel = per lane), residual add (read from
 //     the LDS image being replaced), ReLU, round-to-nearest-even bf16, written straight back into LDS.
 //   * conv_bn of the stem normalises over the board ROW (build_graph.py:68 axis=1): per-row scale/shift.
-// One barrier per layer.  The heads (1x1 convs + dense layers, 47 k MAC/board) run as a second small kernel.
+// One barrier per layer.  The heads (1x1 convs + dense layers, 47 k MAC/board) run at the end of the same launch on the
+// LDS-resident tower output: one kernel = one whole net forward, HBM sees 88 B in and 45 floats out per board.
 #include <stdlib.h>
 #include <string.h>
 
@@ -231,7 +232,8 @@ __global__ __launch_bounds__(1024 / NT, NT == 2 ? 2 : 1) void k_tower_bf16(const
                                                                            const uint16_t* __restrict__ stem_wp,
                                                                            const uint16_t* __restrict__ tower_wp,
                                                                            const float* __restrict__ fold, int blocks,
-                                                                           uint16_t* __restrict__ out,
+                                                                           const float* __restrict__ hp,
+                                                                           float* __restrict__ pi_out, float* __restrict__ v_out,
                                                                            unsigned long long* __restrict__ diag)
 {
     using G = Geo<NB>;
@@ -410,12 +412,69 @@ __global__ __launch_bounds__(1024 / NT, NT == 2 ? 2 : 1) void k_tower_bf16(const
     }
 
     if (diag && blockIdx.x == 0 && tid == 0) { diag[2] = __builtin_amdgcn_s_memtime(); diag[3] = __builtin_amdgcn_s_memrealtime(); }
-    // ---- final activation -> HBM (bf16 [board][42][256]) for the heads kernel
-    for (int i = tid; i < ROWS * 32; i += THREADS) {
-        const int r = i >> 5, seg = i & 31;
-        if (board0 + r / 42 < n) {
-            const uint4 v = *reinterpret_cast<const uint4*>(bufX + r * ROWB + seg * 16);
-            *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(out) + ((size_t)board0 * 42 + r) * 512 + seg * 16) = v;
+    // ---- both heads, fused (build_graph.py:76-90; same arithmetic order as k_heads in azr_net.hip).  The tower output
+    // stays in LDS (bufX); bufT is free and holds the head features.  47 k MAC per board: VALU work.
+    {
+        const float* wpi = hp;              // [256][2]
+        const float* bnpi = wpi + NF * 2;   // g[2] b[2] m[2] v[2]
+        const float* wd = bnpi + 8;         // [84][43]
+        const float* bd = wd + 84 * 43;     // [43]
+        const float* wv = bd + 43;          // [256]
+        const float* bnv = wv + NF;         // g b m v
+        const float* w1 = bnv + 4;          // [42][256]
+        const float* b1 = w1 + 42 * 256;    // [256]
+        const float* w2 = b1 + 256;         // [256]
+        const float* b2 = w2 + 256;         // [1]
+        float* feat = reinterpret_cast<float*>(bufT);   // [NB][128]: 84 policy features, then 42 value features
+        float* hid = feat + NB * 128;                   // [NB][256]
+        float* logit = hid + NB * 256;                  // [NB][64]
+        for (int idx = tid; idx < NB * 126; idx += THREADS) {  // 42 cells x {pi0, pi1, v} per board
+            const int bb = idx / 126, t = idx % 126, pos = t / 3, c = t % 3;
+            const uint16_t* x = reinterpret_cast<const uint16_t*>(bufX + (bb * 42 + pos) * ROWB);
+            float sacc = 0.0f;
+            if (c < 2) for (int ci = 0; ci < NF; ci++) sacc = fmaf(bf2f(x[ci]), wpi[ci * 2 + c], sacc);
+            else for (int ci = 0; ci < NF; ci++) sacc = fmaf(bf2f(x[ci]), wv[ci], sacc);
+            const float* bnp = c < 2 ? bnpi : bnv;
+            const int nc = c < 2 ? 2 : 1, kk = c < 2 ? c : 0;
+            float y = (sacc - bnp[2 * nc + kk]) * (bnp[kk] / sqrtf(bnp[3 * nc + kk] + 1e-3f)) + bnp[nc + kk];
+            y = y > 0.0f ? y : 0.0f;
+            if (c < 2) feat[bb * 128 + pos * 2 + c] = y;  // NHWC flatten: (y*6+x)*2 + c
+            else feat[bb * 128 + 84 + pos] = y;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < NB * 43; idx += THREADS) {
+            const int bb = idx / 43, t = idx % 43;
+            float sacc = 0.0f;
+            for (int i = 0; i < 84; i++) sacc = fmaf(feat[bb * 128 + i], wd[i * 43 + t], sacc);
+            logit[bb * 64 + t] = sacc + bd[t];
+        }
+        for (int idx = tid; idx < NB * 256; idx += THREADS) {
+            const int bb = idx >> 8, t = idx & 255;
+            float sacc = 0.0f;
+            for (int i = 0; i < 42; i++) sacc = fmaf(feat[bb * 128 + 84 + i], w1[i * 256 + t], sacc);
+            sacc += b1[t];
+            hid[idx] = (sacc > 0.0f ? sacc : 0.0f) * w2[t];
+        }
+        __syncthreads();
+        // one wave per (board, head): softmax over the 43 logits / tanh of the 256-term value sum
+        for (int job = wave; job < NB * 2; job += THREADS / 64) {
+            const int bb = job >> 1;
+            if (board0 + bb >= n) continue;
+            if ((job & 1) == 0) {
+                const float lv = lane < 43 ? logit[bb * 64 + lane] : -INFINITY;
+                float mx = lv;
+                for (int sft = 32; sft >= 1; sft >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sft));
+                const float e = lane < 43 ? expf(lv - mx) : 0.0f;
+                float se = e;
+                for (int sft = 32; sft >= 1; sft >>= 1) se += __shfl_xor(se, sft);
+                if (lane < 43) pi_out[(size_t)(board0 + bb) * PI_STRIDE + lane] = e / se;
+                if (lane == 43) pi_out[(size_t)(board0 + bb) * PI_STRIDE + 43] = 0.0f;
+            } else {
+                const float* hb = hid + bb * 256;
+                float sacc = hb[lane] + hb[lane + 64] + hb[lane + 128] + hb[lane + 192];
+                for (int sft = 32; sft >= 1; sft >>= 1) sacc += __shfl_xor(sacc, sft);
+                if (lane == 0) v_out[board0 + bb] = tanhf(sacc + b2[0]);
+            }
         }
     }
 }
@@ -423,7 +482,6 @@ __global__ __launch_bounds__(1024 / NT, NT == 2 ? 2 : 1) void k_tower_bf16(const
 struct Bf16Net {
     uint16_t* stem_wp = nullptr;
     uint16_t* tower_wp = nullptr;
-    uint16_t* act = nullptr;  // [G][42][256] bf16 tower output
     unsigned long long* diag = nullptr;  // set only by azr_debug_tower_clock
 };
 Bf16Net* bn(azr_engine* h) { return reinterpret_cast<Bf16Net*>(h->net.bf16ctx); }
@@ -439,7 +497,6 @@ int net_bf16_alloc(azr_engine* h)
     HIPCHK(h, hipMalloc((void**)&x->stem_wp, STEM_HALFS * 2));
     HIPCHK(h, hipMalloc((void**)&x->tower_wp, ((size_t)2 * B * TOWER_LAYER_HALFS + MAX_RING * KSTRIDE * 8) * 2));  // + ring run-off
     HIPCHK(h, hipMemsetAsync(x->tower_wp, 0, ((size_t)2 * B * TOWER_LAYER_HALFS + MAX_RING * KSTRIDE * 8) * 2, h->stream));
-    HIPCHK(h, hipMalloc((void**)&x->act, (size_t)h->d.G * NPOS * NF * 2));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<1>::LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<2>::LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<3>::LDS_BYTES));
@@ -455,7 +512,6 @@ void net_bf16_free(azr_engine* h)
     Bf16Net* x = bn(h);
     if (x->stem_wp) hipFree(x->stem_wp);
     if (x->tower_wp) hipFree(x->tower_wp);
-    if (x->act) hipFree(x->act);
     delete x;
     h->net.bf16ctx = nullptr;
 }
@@ -510,13 +566,12 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
     const int NT = nt_env == 4 ? 4 : 2;
 #define LAUNCH_TOWER(NBV, NTV)                                                                                      \
     hipLaunchKernelGGL((k_tower_bf16<NBV, NTV>), dim3((n + NBV - 1) / NBV), dim3(1024 / NTV), Geo<NBV>::LDS_BYTES, \
-                       h->stream, d_in88, in_stride, n, x->stem_wp, x->tower_wp, fold, B, x->act, x->diag)
+                       h->stream, d_in88, in_stride, n, x->stem_wp, x->tower_wp, fold, B, net_head_params(h), d_pi, d_v, x->diag)
     if (n <= 256) { if (NT == 2) LAUNCH_TOWER(1, 2); else LAUNCH_TOWER(1, 4); }
     else if (n <= 512) { if (NT == 2) LAUNCH_TOWER(2, 2); else LAUNCH_TOWER(2, 4); }
     else { if (NT == 2) LAUNCH_TOWER(3, 2); else LAUNCH_TOWER(3, 4); }
 #undef LAUNCH_TOWER
     if (h->pe_tower1) hipEventRecord(h->pe_tower1, h->stream);
-    launch_heads_bf16(h->stream, n, x->act, net_head_params(h), d_pi, d_v);
     HIPCHK(h, hipGetLastError());
     return AZR_OK;
 }

@@ -174,7 +174,7 @@ def main():
             "net_evals_per_s": evals / dt, "mean_depth": levels / max(1, sims),
             "games_finished": games, "records_gathered": int(allrecs.shape[0]), "errors": errors,
             "nodes_dropped": dropped,
-            "roofline": {"bound": "mfma", "kernel": "k_tower_bf16 (stem + 2B conv layers of one net forward of G leaves, one launch)"
+            "roofline": {"bound": "mfma", "kernel": "k_tower_bf16 (one whole net forward of G leaves: stem + 2B conv layers + both heads, one launch)"
                          if a.dtype == "bf16" else "fp32 conv chain", "achieved": achieved / 1e12,
                          "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
                          "flop_per_launch": a.games * fps, "avg_launch_ms": prof["net_ms"],
