@@ -296,8 +296,10 @@ class Engine:
         self._chk(self.L.azr_selfplay_counters(self.h, C.byref(c)))
         return c.as_dict()
 
-    def drain(self, cap=1 << 20):
-        buf = np.zeros((cap, RECORD_BYTES), np.uint8)
+    def drain(self, cap=None):
+        if cap is None:
+            cap = max(1, self.samples_device_view()[1])
+        buf = np.empty((cap, RECORD_BYTES), np.uint8)
         n = C.c_size_t(0)
         self._chk(self.L.azr_samples_drain(self.h, _p(buf), cap, C.byref(n)))
         return buf[:n.value].copy()

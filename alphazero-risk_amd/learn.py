@@ -1,0 +1,216 @@
+"""`-m train` / `-m learn`: the reference's learn loop (AlphaZeroTrainer::train, alphazero_trainer.cpp:12-34,121-198)
+over the MI355X engine:
+
+    self-play (device-resident, azr_selfplay_*)  ->  replay buffer (trimOldExamples, alphazero_nn_data.cpp:67-84)
+    ->  train step (train.py, provisional PyTorch-ROCm autograd)  ->  arena new-vs-old through the batched Player seam
+    (two engines = two nets, one tree per player as in the reference)  ->  accept (>= COMPARE_TRESHOLD of decided games)
+    / revert  ->  benchmark vs RandomPlayer(10) and ScriptPlayer(100) on the device arena
+with the reference's log files (log/azr-improvement-log.txt, azr-benchmark-log.txt, azr-nn-training-log.txt) and
+checkpoint names (checkpoints/{latest,best}-checkpoint.bin, checkpoint-iter-N.bin; AZRW container).
+
+    python -m alphazero-risk_amd.learn ...     is not importable as a module name with a hyphen; run
+    python alphazero-risk_amd/learn.py --ti 2 --tg 256 --mcts 100 --gpu-games 256 --blocks 20 --cg 100
+"""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+P = importlib.import_module("alphazero-risk_amd")
+train_mod = importlib.import_module("alphazero-risk_amd.train")
+
+
+# ---- host-side pieces of Game (game/game.cpp) for the two-net arena ---------------------------------------------------
+def invert_players(img):
+    """State::invertPlayers (state.cpp:493-516) on [G,160] Data images"""
+    out = img.copy()
+    la = out[:, :42]
+    owner = la >> 6
+    out[:, :42] = np.where(owner < 2, (la & 63) | ((owner ^ 1) << 6), la)
+    out[:, 48:96], out[:, 96:144] = img[:, 96:144], img[:, 48:96]
+    return out
+
+
+def take_turns(eng, states, me):
+    """AlphaZeroPlayerGroup::takeTurns = batched AlphaZeroPlayer::takeTurn (alphazero_player.cpp:3-21)"""
+    eng.mcts_trim()
+    while True:
+        eng.set_states(states)
+        status = eng.status()
+        mine = (status == -1) & (states[:, 146] == me)
+        if not mine.any():
+            return states
+        eng.simulate()
+        mv = eng.pick(sample=False)
+        mv[~mine] = 255
+        eng.make_moves(mv)
+        states = eng.get_states()
+
+
+def arena_two_nets(eng_new, eng_old, games, mirror=True, base_seed=1):
+    """GameGroup::playGames(trainAZPG, generateAZPG, games) (game.cpp:277-312): player 0 = new net, player 1 = old net.
+    The G slots play mirrored pairs in lock-step.  Returns a GameResults-like dict."""
+    G = eng_new.G
+    res = dict(count=0, draw=0, win=[0, 0], win_and_started=[0, 0])
+    seed = base_seed
+    while True:
+        take = min(G, (games - res["count"]) // 2)   # Counter::hasNext(2): whole pairs only; slot k plays pair k
+        if take == 0:
+            return res
+        eng_new.new_games(np.arange(seed, seed + G, dtype=np.uint32))
+        seed += G
+        start = eng_new.get_states()
+        for player_start in (0, 1):   # Game::newGame (game.cpp:170-191) + incPlayerStart
+            if player_start == 0:
+                states = start.copy()
+            elif mirror:
+                states = invert_players(start)
+            else:
+                eng_new.new_games(np.arange(seed, seed + G, dtype=np.uint32))
+                seed += G
+                states = eng_new.get_states()
+            states[:, 146] = player_start          # State::setCurrentPlayerTurn
+            eng_new.mcts_clear()                   # AlphaZeroPlayer::newGame
+            eng_old.mcts_clear()
+            while True:                            # Game::gameLoop
+                states = take_turns(eng_new, states, 0)
+                states = take_turns(eng_old, states, 1)
+                eng_new.set_states(states)
+                status = eng_new.status()
+                if (status != -1).all():
+                    break
+            for g in range(take):                  # GameResults::addGame (game.cpp:193-213)
+                res["count"] += 1
+                if status[g] == -2:
+                    res["draw"] += 1
+                else:
+                    res["win"][status[g]] += 1
+                    if status[g] == player_start:
+                        res["win_and_started"][status[g]] += 1
+
+
+def is_model_improved(gr, threshold):
+    """AlphaZeroTrainer::isModelImproved (alphazero_trainer.cpp:192-198): `int >= int * float` evaluated in fp32"""
+    return bool(np.float32(gr["win"][0]) >= np.float32(gr["win"][0] + gr["win"][1]) * np.float32(threshold))
+
+
+def gr_str(gr):  # operator<<(GameResults) (game.cpp:227-235)
+    return f"{gr['draw']}, {gr['win'][0]}/{gr['win_and_started'][0]}, {gr['win'][1]}/{gr['win_and_started'][1]}"
+
+
+def trim_old_examples(records, old_game_index, smin, smax):
+    """NNTrainDataStorage::trimOldExamples (alphazero_nn_data.cpp:67-84)"""
+    n = len(records)
+    if n > smax:
+        return records[n - smax:], old_game_index
+    if n > smin and old_game_index > 0:
+        excess = min(old_game_index, n - smin)
+        return records[excess:], old_game_index - excess
+    return records, old_game_index
+
+
+def run_arena(eng, p1, p2, games, mirror, seed):
+    eng.arena_start(p1, p2, games, 0, mirror, seed)
+    while not eng.arena_run(4 * (eng.settings.mcts_simulations + 2)):
+        pass
+    return eng.arena_results()
+
+
+def learn(a, log=print):
+    os.makedirs("log", exist_ok=True)
+    os.makedirs("checkpoints", exist_ok=True)
+    dtype = P.NET_BF16 if a.dtype == "bf16" else P.NET_F32
+    gen = P.Engine(a.gpu_games, blocks=a.blocks, sims=a.mcts, dtype=dtype, device=a.device)
+    new = P.Engine(a.gpu_games, blocks=a.blocks, sims=a.mcts, dtype=dtype, device=a.device)
+    latest, best = "checkpoints/latest-checkpoint.bin", "checkpoints/best-checkpoint.bin"
+    for e in (new, gen):  # loadCheckpoint: missing => init + save (alphazero_nn.cpp:197-202)
+        if os.path.exists(latest):
+            e.load(latest)
+        else:
+            e.init_random(20260002)
+            e.save(latest)
+    trainer = train_mod.Trainer(a.blocks, new.get_weights(), device=f"cuda:{a.device}", batch_size=a.bs, seed=a.seed)
+    records = np.zeros((0, 265), np.uint8)
+    old_game_index = 0
+    imp_log = open("log/azr-improvement-log.txt", "a")
+    bench_log = open("log/azr-benchmark-log.txt", "a")
+    nn_log = open("log/azr-nn-training-log.txt", "a")
+    summary = []
+    for it in range(a.ti):
+        log(f"Train iteration {it}")
+        # ---- generateTrainData (alphazero_trainer.cpp:36-78)
+        t0 = time.time()
+        gen.selfplay_start((a.seed + it * 65536 * a.gpu_games) & 0xFFFFFFFF)
+        new_recs = []
+        while True:
+            gen.selfplay_run(4 * (a.mcts + 2))
+            c = gen.counters()
+            new_recs.append(gen.drain())
+            if c["games_finished"] >= a.tg:
+                break
+        new_recs = np.concatenate(new_recs)
+        dt = time.time() - t0
+        log(f"Generated {len(new_recs)} new samples for total {len(records) + len(new_recs)}  "
+            f"[{c['games_finished']} games, {c['simulations'] / dt:.0f} simulations/s, {c['games_finished'] / dt:.2f} games/s]")
+        records = np.concatenate([records, new_recs])
+        records, old_game_index = trim_old_examples(records, old_game_index, a.s, 16384 * a.bs)
+        # ---- trainGroup->train (alphazero_gpu_cluster.cpp:221-231)
+        hist = trainer.train(records, a.e, nn_log)
+        if hist:
+            log(f"Loss Policy / Value: {hist[-1][0]:f} / {hist[-1][1]:f}")
+        new.set_weights(trainer.flat())
+        # ---- updateIfImprovement (alphazero_trainer.cpp:134-190)
+        improved = True
+        gr = None
+        if a.cg > 0:
+            gr = arena_two_nets(new, gen, a.cg, True, a.seed + 7919 * (it + 1))
+            imp_log.write(f"{it},{gr_str(gr)}\n"); imp_log.flush()
+            improved = is_model_improved(gr, a.ct)
+        if improved:
+            log("Model improved")
+            new.save(best); new.save(f"checkpoints/checkpoint-iter-{it}.bin")
+            gen.load(best)
+            r = run_arena(gen, P.PLAYER_ALPHAZERO, P.PLAYER_RANDOM, 10, True, a.seed + 11)
+            s = run_arena(gen, P.PLAYER_ALPHAZERO, P.PLAYER_SCRIPT, 100, True, a.seed + 13)
+            bench_log.write(f"{it},{gr_str(r)}, {gr_str(s)}\n"); bench_log.flush()
+            log(f"Model benchmark: vs Random {r['win'][0]}/{r['count']}, vs Script {s['win'][0]}/{s['count']}")
+            old_game_index = max(len(records) - 1, 0)   # updateOldGamesIndex
+        else:
+            log("Model did not improve\nModel reverted back old")
+            new.load(latest)
+            trainer.load_flat(new.get_weights())
+        summary.append(dict(iteration=it, samples=len(records), losses=hist, arena=gr, improved=improved))
+    # saveTrainingSamples (reference writer layout: 8-byte count + 265-byte records)
+    os.makedirs("data", exist_ok=True)
+    with open("data/training_samples.bin", "wb") as f:
+        f.write(np.uint64(len(records)).tobytes())
+        f.write(records.tobytes())
+    gen.close(); new.close()
+    return summary
+
+
+def main():
+    ap = argparse.ArgumentParser(description="AlphaZero-Risk learn loop on MI355X (reference flags of src/settings.h)")
+    ap.add_argument("--ti", type=int, default=10000)      # TRAIN_ITERATIONS
+    ap.add_argument("--tg", type=int, default=1000)       # TRAIN_ITERATION_GAMES
+    ap.add_argument("--mcts", type=int, default=32)
+    ap.add_argument("--gpu-games", type=int, default=256)
+    ap.add_argument("--blocks", type=int, default=20)
+    ap.add_argument("-e", type=int, default=10)           # EPOCHS
+    ap.add_argument("--bs", type=int, default=512)
+    ap.add_argument("--cg", type=int, default=1000)       # COMPARE_GAMES
+    ap.add_argument("--ct", type=float, default=0.55)
+    ap.add_argument("-s", type=int, default=1024 * 512)   # SAMPLES_STORAGE_MIN
+    ap.add_argument("--seed", type=int, default=20260001)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--device", type=int, default=0)
+    learn(ap.parse_args())
+
+
+if __name__ == "__main__":
+    main()
