@@ -183,8 +183,8 @@ class Trainer:
                 loss_pi, loss_v, l2 = self.net.losses(xb, pb, zb)
                 (loss_pi + loss_v + l2).backward()
                 self.opt.step()
-                lp += float(loss_pi)
-                lv += float(loss_v)
+                lp += loss_pi.item()
+                lv += loss_v.item()
             if nb:
                 out.append((lp / nb, lv / nb))
                 if log:
