@@ -227,24 +227,21 @@ __device__ __forceinline__ void conv_tower_layer(const uint8_t* IN, const char* 
     }
 }
 
+// the whole network for the NB boards [board0, board0 + NB) of one workgroup
 template <int NB, int NT>
-__global__ __launch_bounds__(1024 / NT, NT == 2 ? 2 : 1) void k_tower_bf16(const uint8_t* __restrict__ in88, int in_stride, int n,
-                                                                           const uint16_t* __restrict__ stem_wp,
-                                                                           const uint16_t* __restrict__ tower_wp,
-                                                                           const float* __restrict__ fold, int blocks,
-                                                                           const float* __restrict__ hp,
-                                                                           float* __restrict__ pi_out, float* __restrict__ v_out,
-                                                                           unsigned long long* __restrict__ diag)
+__device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int board0, const uint8_t* __restrict__ in88, int in_stride,
+                                           int n, const uint16_t* __restrict__ stem_wp, const uint16_t* __restrict__ tower_wp,
+                                           const float* __restrict__ fold, int blocks, const float* __restrict__ hp,
+                                           float* __restrict__ pi_out, float* __restrict__ v_out,
+                                           unsigned long long* __restrict__ diag)
 {
     using G = Geo<NB>;
     constexpr int ROWS = G::ROWS, MT = G::MT, THREADS = 1024 / NT, WCOLS = NT * 16;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t* bufX = lds;
     uint8_t* bufT = lds + G::BUF;
     uint8_t* in_l = lds + G::IN88_OFF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
-    const int board0 = blockIdx.x * NB;
     // clock diagnostic (azr_debug_tower_clock): shader-clock and 100 MHz real-time stamps around the whole tower of
     // workgroup 0; `diag` is null in every product launch
     if (diag && blockIdx.x == 0 && tid == 0) { diag[0] = __builtin_amdgcn_s_memtime(); diag[1] = __builtin_amdgcn_s_memrealtime(); }
@@ -479,6 +476,30 @@ __global__ __launch_bounds__(1024 / NT, NT == 2 ? 2 : 1) void k_tower_bf16(const
     }
 }
 
+// Workgroups [0, n_full) carry NB boards, the rest NB - 1: a batch that is not a whole number of 256-workgroup waves of
+// NB boards is split into whole waves of mixed size instead (2048 boards = 512 x 3 + 256 x 2: each CU slot runs 3 + 3 + 2
+// boards rather than a 2.67-wave tail).  NB - 1 runs the NB - 1 instantiation of the same body inside this kernel's LDS.
+template <int NB, int NT>
+__global__ __launch_bounds__(1024 / NT, NT == 2 ? 2 : 1) void k_tower_bf16(const uint8_t* __restrict__ in88, int in_stride, int n,
+                                                                           const uint16_t* __restrict__ stem_wp,
+                                                                           const uint16_t* __restrict__ tower_wp,
+                                                                           const float* __restrict__ fold, int blocks,
+                                                                           const float* __restrict__ hp,
+                                                                           float* __restrict__ pi_out, float* __restrict__ v_out,
+                                                                           unsigned long long* __restrict__ diag, int n_full)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int bid = blockIdx.x;
+    if constexpr (NB == 3) {
+        if (bid >= n_full) {
+            tower_body<NB - 1, NT>(lds, n_full * NB + (bid - n_full) * (NB - 1), in88, in_stride, n, stem_wp, tower_wp, fold, blocks, hp,
+                                   pi_out, v_out, diag);
+            return;
+        }
+    }
+    tower_body<NB, NT>(lds, bid * NB, in88, in_stride, n, stem_wp, tower_wp, fold, blocks, hp, pi_out, v_out, diag);
+}
+
 struct Bf16Net {
     uint16_t* stem_wp = nullptr;
     uint16_t* tower_wp = nullptr;
@@ -565,11 +586,18 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
     static const int nt_env = getenv("AZR_TOWER_NT") ? atoi(getenv("AZR_TOWER_NT")) : 0;
     const int NT = nt_env == 4 ? 4 : 2;
 #define LAUNCH_TOWER(NBV, NTV)                                                                                      \
-    hipLaunchKernelGGL((k_tower_bf16<NBV, NTV>), dim3((n + NBV - 1) / NBV), dim3(1024 / NTV), Geo<NBV>::LDS_BYTES, \
-                       h->stream, d_in88, in_stride, n, x->stem_wp, x->tower_wp, fold, B, net_head_params(h), d_pi, d_v, x->diag)
-    if (n <= 256) { if (NT == 2) LAUNCH_TOWER(1, 2); else LAUNCH_TOWER(1, 4); }
-    else if (n <= 512) { if (NT == 2) LAUNCH_TOWER(2, 2); else LAUNCH_TOWER(2, 4); }
-    else { if (NT == 2) LAUNCH_TOWER(3, 2); else LAUNCH_TOWER(3, 4); }
+    hipLaunchKernelGGL((k_tower_bf16<NBV, NTV>), dim3(wgs), dim3(1024 / NTV), Geo<NBV>::LDS_BYTES,                 \
+                       h->stream, d_in88, in_stride, n, x->stem_wp, x->tower_wp, fold, B, net_head_params(h), d_pi, d_v, x->diag, n_full)
+    int wgs, n_full;
+    if (n <= 256) { wgs = n_full = n; if (NT == 2) LAUNCH_TOWER(1, 2); else LAUNCH_TOWER(1, 4); }
+    else if (n <= 512) { wgs = n_full = (n + 1) / 2; if (NT == 2) LAUNCH_TOWER(2, 2); else LAUNCH_TOWER(2, 4); }
+    else {
+        // whole waves of 256 workgroups with a 3/2-board mix when the batch allows it (2W <= n <= 3W)
+        const int W = 256 * ((n + 767) / 768);
+        if (2 * W <= n && !getenv("AZR_TOWER_NOMIX")) { wgs = W; n_full = n - 2 * W; }
+        else { wgs = n_full = (n + 2) / 3; }
+        if (NT == 2) LAUNCH_TOWER(3, 2); else LAUNCH_TOWER(3, 4);
+    }
 #undef LAUNCH_TOWER
     if (h->pe_tower1) hipEventRecord(h->pe_tower1, h->stream);
     HIPCHK(h, hipGetLastError());

@@ -64,11 +64,11 @@ def test_checkpoint_roundtrip(tmp_path):
     eng.close()
 
 
-@pytest.mark.parametrize("n,blocks", [(48, 2), (300, 2), (600, 1), (16, 20)])
+@pytest.mark.parametrize("n,blocks", [(48, 2), (300, 2), (600, 1), (1100, 1), (16, 20)])
 def test_bf16_mfma_tower_matches_fp32_oracle(orc, n, blocks):
     """bf16 MFMA path (bf16 weights and inter-layer activations, fp32 accumulate/epilogue) vs the fp32 oracle.
     Stated tolerance: max |dpi| <= 2e-2, max |dv| <= 2e-2; typical error is ~1e-3.
-    n selects the 1-, 2- and 3-boards-per-workgroup variants (M = 48 / 96 / 128)."""
+    n selects the 1-, 2- and 3-boards-per-workgroup variants (M = 48 / 96 / 128) and the mixed 3/2 launch."""
     P = pkg()
     base = sample_inputs(64)
     x = np.concatenate([base] * ((n + 63) // 64))[:n].copy()
@@ -83,8 +83,10 @@ def test_bf16_mfma_tower_matches_fp32_oracle(orc, n, blocks):
     assert dpi <= 2e-2 and dv <= 2e-2, (dpi, dv)
     assert np.allclose(pi.sum(1), 1.0, atol=1e-5)
     # identical inputs in different slots / workgroup shapes give identical bits (batch invariance)
-    if n > 64:
-        assert (pi[:64].view(np.uint32) == pi[64:128].view(np.uint32)).all() or n < 128
+    # (n = 600 / 1100 run the mixed launch: 3-board workgroups first, 2-board workgroups after)
+    for k in range(64, n - 63, 64):
+        assert (pi[:64].view(np.uint32) == pi[k:k + 64].view(np.uint32)).all(), k
+        assert (v[:64] == v[k:k + 64]).all(), k
     p1, v1 = eng.predict(x[:3])
     assert (p1.view(np.uint32) == pi[:3].view(np.uint32)).all() and (v1 == v[:3]).all()
     eng.close()
