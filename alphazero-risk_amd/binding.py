@@ -62,7 +62,7 @@ EXPORTS = [
     "azr_engine_new_games", "azr_engine_set_states", "azr_engine_get_states", "azr_engine_set_rng", "azr_engine_get_rng",
     "azr_engine_valid_moves", "azr_engine_make_moves", "azr_engine_status", "azr_engine_encode",
     "azr_nn_param_count", "azr_nn_init_random", "azr_nn_set_weights", "azr_nn_get_weights", "azr_nn_load", "azr_nn_save",
-    "azr_nn_predict", "azr_mcts_clear", "azr_mcts_trim", "azr_mcts_simulate", "azr_mcts_begin", "azr_mcts_leaves",
+    "azr_nn_predict", "azr_nn_train", "azr_nn_train_batch", "azr_nn_train_grads", "azr_nn_train_reset", "azr_mcts_clear", "azr_mcts_trim", "azr_mcts_simulate", "azr_mcts_begin", "azr_mcts_leaves",
     "azr_mcts_apply", "azr_mcts_root_stats", "azr_mcts_policy", "azr_mcts_pick", "azr_selfplay_start", "azr_selfplay_run",
     "azr_selfplay_counters", "azr_samples_drain", "azr_samples_device_view", "azr_profile_last_run",
     "azr_device_synchronize", "azr_arena_start", "azr_arena_run", "azr_arena_results", "azr_arena_log",
@@ -93,6 +93,10 @@ def load_library():
         L.azr_nn_load.argtypes = [C.c_void_p, C.c_char_p]
         L.azr_nn_save.argtypes = [C.c_void_p, C.c_char_p]
         L.azr_nn_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.azr_nn_train.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.azr_nn_train_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.azr_nn_train_grads.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.azr_nn_train_reset.argtypes = [C.c_void_p]
         L.azr_selfplay_start.argtypes = [C.c_void_p, C.c_uint32]
         L.azr_selfplay_run.argtypes = [C.c_void_p, C.c_int]
         L.azr_samples_drain.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -240,6 +244,31 @@ class Engine:
         v = np.zeros(n, np.float32)
         self._chk(self.L.azr_nn_predict(self.h, _p(x), n, _p(pi), _p(v)))
         return pi, v
+
+    def train(self, rec265, epochs, batch_size=512, rng_state=None):
+        """AlphaZeroNNId::train: returns ([(loss_pi, loss_v)] per epoch, engine state after the shuffles)"""
+        r = np.ascontiguousarray(rec265, np.uint8).reshape(-1, 265)
+        lp = np.zeros(max(epochs, 1), np.float32)
+        lv = np.zeros(max(epochs, 1), np.float32)
+        st = np.array([rng_state if rng_state is not None else 1], np.uint32)
+        self._chk(self.L.azr_nn_train(self.h, _p(r), len(r), epochs, batch_size, _p(st) if rng_state is not None else None,
+                                      _p(lp), _p(lv)))
+        return [(float(lp[e]), float(lv[e])) for e in range(epochs)], int(st[0])
+
+    def train_batch(self, rec265):
+        """one optimiser step on exactly these records; returns (loss_pi, loss_v)"""
+        r = np.ascontiguousarray(rec265, np.uint8).reshape(-1, 265)
+        l = np.zeros(2, np.float32)
+        self._chk(self.L.azr_nn_train_batch(self.h, _p(r), len(r), _p(l[0:1]), _p(l[1:2])))
+        return float(l[0]), float(l[1])
+
+    def train_grads(self):
+        g = np.zeros(self.L.azr_nn_param_count(self.settings.blocks), np.float32)
+        self._chk(self.L.azr_nn_train_grads(self.h, _p(g), g.size))
+        return g
+
+    def train_reset(self):
+        self._chk(self.L.azr_nn_train_reset(self.h))
 
     # ---- search
     def mcts_clear(self):

@@ -783,6 +783,7 @@ extern "C" int azr_engine_destroy(azr_engine* h)
                     d.leaf_valid, d.leaf_hash, d.net_pi, d.net_v, d.stage, d.ring, d.ring_count, d.counters, d.active,
                     d.arena_taken, d.arena_res, d.prev_start, d.script, d.alog_status, d.alog_rounds, d.alog_final};
     for (void* p : ptrs) if (p) hipFree(p);
+    train_free(h);
     net_free(h);
     for (hipEvent_t e : h->ev) hipEventDestroy(e);
     hipStreamDestroy(h->stream);

@@ -94,6 +94,7 @@ struct azr_engine {
     hipEvent_t pe_tower0 = nullptr, pe_tower1 = nullptr;  // when set, the net records these around its dominant kernel
     int prof_launches;
     bool weights_set;
+    void* train = nullptr;        // azr_train.hip: optimiser state + activation slabs, created by the first azr_nn_train*
 };
 
 namespace azr {
@@ -104,4 +105,6 @@ int net_upload(azr_engine* h);  // fold BN, pack, copy h->flat to the device
 int net_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v);
 size_t net_param_count(int blocks);
 void net_init_random(float* flat, int blocks, uint64_t seed);
+// train (azr_train.hip)
+void train_free(azr_engine* h);
 }  // namespace azr

@@ -490,7 +490,7 @@ __global__ __launch_bounds__(1024 / NT, NT == 2 ? 2 : 1) void k_tower_bf16(const
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int bid = blockIdx.x;
-    if constexpr (NB == 3) {
+    if constexpr (NB >= 2) {
         if (bid >= n_full) {
             tower_body<NB - 1, NT>(lds, n_full * NB + (bid - n_full) * (NB - 1), in88, in_stride, n, stem_wp, tower_wp, fold, blocks, hp,
                                    pi_out, v_out, diag);
@@ -588,16 +588,17 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
 #define LAUNCH_TOWER(NBV, NTV)                                                                                      \
     hipLaunchKernelGGL((k_tower_bf16<NBV, NTV>), dim3(wgs), dim3(1024 / NTV), Geo<NBV>::LDS_BYTES,                 \
                        h->stream, d_in88, in_stride, n, x->stem_wp, x->tower_wp, fold, B, net_head_params(h), d_pi, d_v, x->diag, n_full)
-    int wgs, n_full;
-    if (n <= 256) { wgs = n_full = n; if (NT == 2) LAUNCH_TOWER(1, 2); else LAUNCH_TOWER(1, 4); }
-    else if (n <= 512) { wgs = n_full = (n + 1) / 2; if (NT == 2) LAUNCH_TOWER(2, 2); else LAUNCH_TOWER(2, 4); }
-    else {
-        // whole waves of 256 workgroups with a 3/2-board mix when the batch allows it (2W <= n <= 3W)
-        const int W = 256 * ((n + 767) / 768);
-        if (2 * W <= n && !getenv("AZR_TOWER_NOMIX")) { wgs = W; n_full = n - 2 * W; }
-        else { wgs = n_full = (n + 2) / 3; }
-        if (NT == 2) LAUNCH_TOWER(3, 2); else LAUNCH_TOWER(3, 4);
-    }
+    // One workgroup per CU is resident (LDS and VGPR budget), so the batch is cut into r rounds of 256 workgroups and
+    // the boards are dealt as evenly as 1..3 per workgroup allows: `n_full` workgroups of nb boards first, the rest nb - 1.
+    const int rounds = (n + 767) / 768, W = 256 * rounds;
+    int wgs = W, nb = n / W, n_full = n % W;
+    if (nb == 0) { nb = 1; wgs = n_full = n; }          // fewer boards than CUs: one each
+    else if (n_full == 0) n_full = W;                  // exact multiple: all workgroups carry nb
+    else nb += 1;
+    if (getenv("AZR_TOWER_NOMIX")) { nb = n <= 256 ? 1 : n <= 512 ? 2 : 3; wgs = n_full = (n + nb - 1) / nb; }
+    if (nb == 1) { if (NT == 2) LAUNCH_TOWER(1, 2); else LAUNCH_TOWER(1, 4); }
+    else if (nb == 2) { if (NT == 2) LAUNCH_TOWER(2, 2); else LAUNCH_TOWER(2, 4); }
+    else { if (NT == 2) LAUNCH_TOWER(3, 2); else LAUNCH_TOWER(3, 4); }
 #undef LAUNCH_TOWER
     if (h->pe_tower1) hipEventRecord(h->pe_tower1, h->stream);
     HIPCHK(h, hipGetLastError());

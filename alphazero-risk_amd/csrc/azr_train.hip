@@ -1,0 +1,1099 @@
+// azr_train.hip — the optimiser step of the learn loop on the GPU (SURVEY §8 f-2, C-ABI azr_nn_train*).
+//
+// Replaces AlphaZeroNN::train (neural_network/alphazero_nn.cpp:351-410), i.e. `session->Run({state, target pi, target v,
+// training=true}, {loss_policy, loss_value}, {optimize})` on the graph of python/src/build_graph.py:54-103:
+//   forward in training mode (batch-statistics BN, moving averages updated with momentum 0.99), loss =
+//   softmax-CE(pi) + MSE(v) + 1e-3 * sum ||kernel||^2, backward, Adam(1e-3, .9, .999, 1e-8) — all fp32 like the
+//   reference's TF session.
+//
+// Data layout (all fp32, row-major): an activation is [M = batch * 42 rows][256 channels], row = board * 42 + y * 6 + x —
+// the inference kernels' row order.  A 3x3 SAME convolution is  im2col ([M][9 * Cin])  x  W ([9 * Cin][256], which is the
+// AZRW kernel [tap][ci][co] as it lies in the flat vector)  on the fp32 MFMA (v_mfma_f32_32x32x2_f32); its two
+// gradients are the same GEMM kernel with transposed operand access (dcol = dY x W^T, dW = col^T x dY, split-K).
+// Every conv output (pre-BN) and every post-activation is kept for the backward pass: 2 x 22 MB per layer at batch 512,
+// 1.8 GB for the 41 conv layers of B = 20 — sized for 288 GB of HBM, nothing is recomputed.
+// Reductions (BN statistics, bias / BN / head gradients, split-K) are two-stage and atomic-free: a step is
+// bit-reproducible.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <random>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "azr_internal.hpp"
+
+using namespace azr;
+
+#define HIPCHK(h, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
+            return AZR_E_HIP;                                                                   \
+        }                                                                                       \
+    } while (0)
+
+namespace {
+
+constexpr int KC = 9 * NF;        // im2col row length of a tower conv
+constexpr int SIN = 16;           // stem input planes padded 13 -> 16
+constexpr int KS = 9 * SIN;       // im2col row length of the stem conv
+constexpr float BN_EPS = 1e-3f;   // tf.layers.batch_normalization epsilon
+constexpr float BN_KEEP = 0.99f;  // momentum
+constexpr float L2_C = 1e-3f;     // REGULARIZATION_L2_C (build_graph.py:30)
+constexpr float LR = 1e-3f, ADAM_B1 = 0.9f, ADAM_B2 = 0.999f, ADAM_EPS = 1e-8f;  // build_graph.py:31,103
+constexpr int RB = 64;            // rows per block in the two-stage reductions
+
+// AZRW offsets (same arithmetic as azr_net.hip)
+constexpr size_t LAYER = (size_t)9 * NF * NF + 4 * NF;
+constexpr size_t OFF_STEM_BN = 9 * 13 * NF;
+constexpr size_t OFF_BLOCK0 = OFF_STEM_BN + 28;
+// head section
+constexpr int H_PI_W = 0, H_PI_BN = 512, H_PD_W = 520, H_PD_B = 4132, H_V_W = 4175, H_V_BN = 4431, H_V1_W = 4435,
+              H_V1_B = 15187, H_V2_W = 15443, H_V2_B = 15699, HEAD_FLOATS = 15700;
+// per-board dense-gradient partials (t_head_bwd): pd_w | pd_b | v1_w | v1_b | v2_w | v2_b
+constexpr int HP_PD_W = 0, HP_PD_B = 3612, HP_V1_W = 3655, HP_V1_B = 14407, HP_V2_W = 14663, HP_V2_B = 14919, HP_FLOATS = 14920;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// =====================================================================================================================
+// GEMM  C[M][N] = A[M][K] x B[K][N]  on v_mfma_f32_32x32x2_f32.  128x128 block tile, 4 waves of 64x64 (2x2 MFMA tiles),
+// k-tile 16 staged in LDS as [k][m|n] so an MFMA operand read is 32 consecutive floats.  Operand storage is a template
+// switch: A_MCONTIG = A stored [K][M] (column access of a row-major matrix, used for col^T), B_KCONTIG = B stored [N][K]
+// (W^T).  blockIdx.z = split-K slice writing C + z * strideCz.  All edges are bounds-checked.
+// =====================================================================================================================
+constexpr int GT = 128, GK = 16, GLD = GT + 4;
+
+template <bool MN_CONTIG>
+__device__ __forceinline__ void gt_load(const float* __restrict__ P, int ld, int mn0, int k0, int MN, int Kend, int t, float (&r)[8])
+{
+    if constexpr (MN_CONTIG) {  // storage [k][mn]
+        const int k = k0 + (t >> 4), mn = mn0 + (t & 15) * 8;
+        const float* p = P + (size_t)k * ld + mn;
+        if (k < Kend && mn + 7 < MN) {
+            const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+            r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = (k < Kend && mn + j < MN) ? p[j] : 0.0f;
+        }
+    } else {  // storage [mn][k]
+        const int mn = mn0 + (t >> 1), k = k0 + (t & 1) * 8;
+        const float* p = P + (size_t)mn * ld + k;
+        if (mn < MN && k + 7 < Kend) {
+            const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+            r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = (mn < MN && k + j < Kend) ? p[j] : 0.0f;
+        }
+    }
+}
+
+template <bool MN_CONTIG>
+__device__ __forceinline__ void gt_store(float* S, int t, const float (&r)[8])
+{
+    if constexpr (MN_CONTIG) {
+        float* p = S + (t >> 4) * GLD + (t & 15) * 8;
+        *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(r[4], r[5], r[6], r[7]);
+    } else {
+        float* p = S + ((t & 1) * 8) * GLD + (t >> 1);
+#pragma unroll
+        for (int j = 0; j < 8; j++) p[j * GLD] = r[j];
+    }
+}
+
+template <bool A_MCONTIG, bool B_KCONTIG>
+__global__ __launch_bounds__(256) void t_gemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                              float* __restrict__ C, int ldc, int M, int N, int K, int kchunk, size_t strideCz)
+{
+    __shared__ __attribute__((aligned(16))) float As[GK * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[GK * GLD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+    float ra[8], rb[8];
+    gt_load<A_MCONTIG>(A, lda, m0, kbeg, M, kend, t, ra);
+    gt_load<!B_KCONTIG>(B, ldb, n0, kbeg, N, kend, t, rb);
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+        __syncthreads();
+        gt_store<A_MCONTIG>(As, t, ra);
+        gt_store<!B_KCONTIG>(Bs, t, rb);
+        __syncthreads();
+        if (k0 + GK < kend) {
+            gt_load<A_MCONTIG>(A, lda, m0, k0 + GK, M, kend, t, ra);
+            gt_load<!B_KCONTIG>(B, ldb, n0, k0 + GK, N, kend, t, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < GK / 2; kk++) {
+            const int k = kk * 2 + (lane >> 5);
+            const float a0 = As[k * GLD + wm * 64 + (lane & 31)], a1 = As[k * GLD + wm * 64 + 32 + (lane & 31)];
+            const float b0 = Bs[k * GLD + wn * 64 + (lane & 31)], b1 = Bs[k * GLD + wn * 64 + 32 + (lane & 31)];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    float* Cz = C + (size_t)blockIdx.z * strideCz;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = m0 + wm * 64 + i * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+                const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+                if (row < M && col < N) Cz[(size_t)row * ldc + col] = acc[i][j][e];
+            }
+}
+
+// out[i] = sum_z part[z][i]
+__global__ void t_sum_slices(const float* __restrict__ part, int nz, size_t n, float* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int z = 0; z < nz; z++) s += part[(size_t)z * n + i];
+    out[i] = s;
+}
+
+// =====================================================================================================================
+// data movement
+// =====================================================================================================================
+// records [n][265] (i8 player | in88 | f32 z | f32 pi[43]; alphazero_nn_data.h:111-141) -> minibatch tensors
+__global__ void t_gather(const uint8_t* __restrict__ rec, const int* __restrict__ perm, int BS, uint8_t* __restrict__ in88,
+                         float* __restrict__ pit, float* __restrict__ zt)
+{
+    const int b = blockIdx.x, t = threadIdx.x;
+    const uint8_t* r = rec + (size_t)perm[b] * 265;
+    for (int i = t; i < 88; i += blockDim.x) in88[b * 88 + i] = r[1 + i];
+    for (int i = t; i < 44; i += blockDim.x) {
+        float f;
+        memcpy(&f, r + 89 + 4 * i, 4);
+        if (i == 0) zt[b] = f; else pit[b * 43 + i - 1] = f;
+    }
+}
+
+// setInStateTensor (alphazero_nn.cpp:31-67): in88 -> [M][16] planes (13 used)
+__global__ void t_planes(const uint8_t* __restrict__ in88, int M, float* __restrict__ X0)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * SIN) return;
+    const int r = i / SIN, c = i % SIN, b = r / NPOS, pos = r % NPOS;
+    const uint8_t* in = in88 + (size_t)b * 88;
+    float v = 0.0f;
+    if (c < 13) {
+        const uint32_t la = in[pos];
+        const int army = la & 63, owner = la >> 6, cur = in[42], enemy = cur == 0 ? 1 : 0;
+        const float fa = (float)army / 32.0f;
+        float f[10];
+        memcpy(f, in + 48, 40);
+        switch (c) {
+        case 0: v = owner == cur ? fa : 0.0f; break;
+        case 1: v = owner == enemy ? fa : 0.0f; break;
+        case 2: v = owner == 2 ? fa : 0.0f; break;
+        case 3: v = f[9]; break;
+        case 4: v = f[0]; break;
+        case 5: v = f[1]; break;
+        case 6: v = f[2]; break;
+        default: v = f[3 + (c - 7)]; break;
+        }
+    }
+    X0[i] = v;
+}
+
+// stem kernel [9][13][256] <-> padded [9][16][256]
+__global__ void t_stem_pad(const float* __restrict__ w, float* __restrict__ wp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= KS * NF) return;
+    const int co = i % NF, ci = (i / NF) % SIN, tap = i / (NF * SIN);
+    wp[i] = ci < 13 ? w[((size_t)tap * 13 + ci) * NF + co] : 0.0f;
+}
+__global__ void t_stem_unpad(const float* __restrict__ gp, float* __restrict__ g)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 9 * 13 * NF) return;
+    const int co = i % NF, ci = (i / NF) % 13, tap = i / (NF * 13);
+    g[i] = gp[((size_t)tap * SIN + ci) * NF + co];
+}
+
+// col[r][tap][c] = A[r + dy*6 + dx][c] inside the board, else 0   (tap = (dy+1)*3 + (dx+1))
+template <int C>
+__global__ __launch_bounds__(256) void t_im2col(const float* __restrict__ A, float* __restrict__ col, int M)
+{
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (idx >= M * 9) return;
+    const int r = idx / 9, tap = idx % 9, dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const int pos = r % NPOS, y = pos / 6 + dy, x = pos % 6 + dx;
+    const bool ok = y >= 0 && y < 7 && x >= 0 && x < 6;
+    const float4* src = reinterpret_cast<const float4*>(A) + (size_t)(r + dy * 6 + dx) * (C / 4);
+    float4* dst = reinterpret_cast<float4*>(col) + (size_t)idx * (C / 4);
+    for (int q = lane; q < C / 4; q += 64) dst[q] = ok ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// dA[r][c] = sum_tap dcol[r - off(tap)][tap][c] (+ dS[r][c]): the transpose of t_im2col<256>
+__global__ __launch_bounds__(256) void t_col2im(const float* __restrict__ dcol, const float* __restrict__ dS, float* __restrict__ dA, int M)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= M) return;
+    const int pos = r % NPOS, y0 = pos / 6, x0 = pos % 6;
+    float4 acc = dS ? reinterpret_cast<const float4*>(dS)[(size_t)r * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1, y = y0 - dy, x = x0 - dx;
+        if (y >= 0 && y < 7 && x >= 0 && x < 6) {
+            const float4 v = reinterpret_cast<const float4*>(dcol)[((size_t)(r - dy * 6 - dx) * 9 + tap) * 64 + lane];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    reinterpret_cast<float4*>(dA)[(size_t)r * 64 + lane] = acc;
+}
+
+// =====================================================================================================================
+// batch normalisation, training mode.  STEM = the conv_bn layer normalising over axis 1 = board row y (7 groups,
+// build_graph.py:68); otherwise per channel.  Stage 1: per block of RB rows, thread c accumulates in double; stage 2: one
+// block sums the partials.
+// =====================================================================================================================
+constexpr int NG = 7;  // stem groups
+
+// sum of v over the 4 row-groups q = t >> 8 of a 1024-thread block, per channel c = t & 255 (result valid where q == 0)
+__device__ __forceinline__ double reduce_q4(double v, double* sh)
+{
+    const int t = threadIdx.x;
+    __syncthreads();
+    sh[t] = v;
+    __syncthreads();
+    if (t < 256) v = sh[t] + sh[t + 256] + sh[t + 512] + sh[t + 768];
+    return v;
+}
+
+__device__ __forceinline__ double block_sum_1024(double v, double* sh)
+{
+    const int t = threadIdx.x;
+    __syncthreads();
+    sh[t] = v;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (t < o) sh[t] += sh[t + o];
+        __syncthreads();
+    }
+    return sh[0];
+}
+
+template <bool STEM>
+__global__ __launch_bounds__(1024) void t_bn_stats(const float* __restrict__ Y, int M, double* __restrict__ part)
+{
+    __shared__ double sh[1024];
+    const int c = threadIdx.x & 255, q = threadIdx.x >> 8, r0 = blockIdx.x * RB, r1 = min(M, r0 + RB);
+    if constexpr (!STEM) {
+        double s = 0.0, ss = 0.0;
+#pragma unroll 4
+        for (int r = r0 + q; r < r1; r += 4) { const double v = Y[(size_t)r * NF + c]; s += v; ss += v * v; }
+        s = reduce_q4(s, sh);
+        ss = reduce_q4(ss, sh);
+        if (q == 0) {
+            part[((size_t)blockIdx.x * 2 + 0) * NF + c] = s;
+            part[((size_t)blockIdx.x * 2 + 1) * NF + c] = ss;
+        }
+    } else {
+        double s[NG], ss[NG];
+#pragma unroll
+        for (int g = 0; g < NG; g++) s[g] = ss[g] = 0.0;
+        for (int r = r0 + q; r < r1; r += 4) {
+            const double v = Y[(size_t)r * NF + c];
+            const int y = (r % NPOS) / 6;
+#pragma unroll
+            for (int g = 0; g < NG; g++) { s[g] += y == g ? v : 0.0; ss[g] += y == g ? v * v : 0.0; }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            const double a = reduce_q4(s[g], sh), b = reduce_q4(ss[g], sh);
+            if (q == 0) {
+                part[((size_t)blockIdx.x * 2 * NG + g) * NF + c] = a;
+                part[((size_t)blockIdx.x * 2 * NG + NG + g) * NF + c] = b;
+            }
+        }
+    }
+}
+
+// mean / 1/sqrt(var+eps) of the batch + moving-average update (TF fused BN: moving variance gets Bessel's correction)
+template <bool STEM>
+__global__ __launch_bounds__(1024) void t_bn_finalize(const double* __restrict__ part, int R, double count, float* __restrict__ mean,
+                                                      float* __restrict__ istd, float* __restrict__ bn /* g|b|mu|var */)
+{
+    __shared__ double sh[1024];
+    const int c = threadIdx.x & 255, q = threadIdx.x >> 8;
+    if constexpr (!STEM) {
+        double s = 0.0, ss = 0.0;
+        for (int b = q; b < R; b += 4) { s += part[((size_t)b * 2 + 0) * NF + c]; ss += part[((size_t)b * 2 + 1) * NF + c]; }
+        s = reduce_q4(s, sh);
+        ss = reduce_q4(ss, sh);
+        if (q == 0) {
+            const double mu = s / count, var = fmax(ss / count - mu * mu, 0.0);
+            mean[c] = (float)mu;
+            istd[c] = (float)(1.0 / sqrt(var + (double)BN_EPS));
+            bn[2 * NF + c] = bn[2 * NF + c] * BN_KEEP + (float)mu * (1.0f - BN_KEEP);
+            bn[3 * NF + c] = bn[3 * NF + c] * BN_KEEP + (float)(var * count / (count - 1.0)) * (1.0f - BN_KEEP);
+        }
+    } else {
+        for (int g = 0; g < NG; g++) {
+            double s = 0.0, ss = 0.0;
+            for (int b = q; b < R; b += 4) {
+                s += part[((size_t)b * 2 * NG + g) * NF + c];
+                ss += part[((size_t)b * 2 * NG + NG + g) * NF + c];
+            }
+            s = block_sum_1024(s, sh);
+            ss = block_sum_1024(ss, sh);
+            if (threadIdx.x == 0) {
+                const double mu = s / count, var = fmax(ss / count - mu * mu, 0.0);
+                mean[g] = (float)mu;
+                istd[g] = (float)(1.0 / sqrt(var + (double)BN_EPS));
+                bn[2 * NG + g] = bn[2 * NG + g] * BN_KEEP + (float)mu * (1.0f - BN_KEEP);
+                bn[3 * NG + g] = bn[3 * NG + g] * BN_KEEP + (float)(var * count / (count - 1.0)) * (1.0f - BN_KEEP);
+            }
+        }
+    }
+}
+
+// A = relu(gamma * (Y - mean) * istd + beta (+ S))
+template <bool STEM>
+__global__ __launch_bounds__(256) void t_bn_apply(const float* __restrict__ Y, const float* __restrict__ mean, const float* __restrict__ istd,
+                                                  const float* __restrict__ bn, const float* __restrict__ S, float* __restrict__ A, int M)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
+    if (i >= (size_t)M * (NF / 4)) return;
+    const int r = (int)(i / (NF / 4)), c4 = (int)(i % (NF / 4)) * 4;
+    const int CH = STEM ? NG : NF;
+    const float4 y = reinterpret_cast<const float4*>(Y)[i];
+    const float4 s = S ? reinterpret_cast<const float4*>(S)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float yy[4] = {y.x, y.y, y.z, y.w}, sv[4] = {s.x, s.y, s.z, s.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int ch = STEM ? (r % NPOS) / 6 : c4 + j;
+        const float v = bn[ch] * ((yy[j] - mean[ch]) * istd[ch]) + bn[CH + ch] + sv[j];
+        o[j] = v > 0.0f ? v : 0.0f;
+    }
+    reinterpret_cast<float4*>(A)[i] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// backward stage 1: dz = dOut * (Apost > 0); partial sums of dz and dz * xhat
+template <bool STEM>
+__global__ __launch_bounds__(1024) void t_bn_bwd_stats(const float* __restrict__ dOut, const float* __restrict__ Apost,
+                                                       const float* __restrict__ Y, const float* __restrict__ mean,
+                                                       const float* __restrict__ istd, int M, double* __restrict__ part)
+{
+    __shared__ double sh[1024];
+    const int c = threadIdx.x & 255, q = threadIdx.x >> 8, r0 = blockIdx.x * RB, r1 = min(M, r0 + RB);
+    if constexpr (!STEM) {
+        const float mu = mean[c], is = istd[c];
+        double s = 0.0, sx = 0.0;
+#pragma unroll 4
+        for (int r = r0 + q; r < r1; r += 4) {
+            const size_t i = (size_t)r * NF + c;
+            const float dz = Apost[i] > 0.0f ? dOut[i] : 0.0f;
+            s += dz;
+            sx += (double)dz * (double)((Y[i] - mu) * is);
+        }
+        s = reduce_q4(s, sh);
+        sx = reduce_q4(sx, sh);
+        if (q == 0) {
+            part[((size_t)blockIdx.x * 2 + 0) * NF + c] = s;
+            part[((size_t)blockIdx.x * 2 + 1) * NF + c] = sx;
+        }
+    } else {
+        double s[NG], sx[NG];
+#pragma unroll
+        for (int g = 0; g < NG; g++) s[g] = sx[g] = 0.0;
+        for (int r = r0 + q; r < r1; r += 4) {
+            const size_t i = (size_t)r * NF + c;
+            const int y = (r % NPOS) / 6;
+            const float dz = Apost[i] > 0.0f ? dOut[i] : 0.0f;
+            const double x = (double)dz * (double)((Y[i] - mean[y]) * istd[y]);
+#pragma unroll
+            for (int g = 0; g < NG; g++) { s[g] += y == g ? (double)dz : 0.0; sx[g] += y == g ? x : 0.0; }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            const double a = reduce_q4(s[g], sh), b = reduce_q4(sx[g], sh);
+            if (q == 0) {
+                part[((size_t)blockIdx.x * 2 * NG + g) * NF + c] = a;
+                part[((size_t)blockIdx.x * 2 * NG + NG + g) * NF + c] = b;
+            }
+        }
+    }
+}
+
+// backward stage 2: d(beta) = sum dz, d(gamma) = sum dz * xhat -> gradient vector; sums[0|1][ch] kept for stage 3
+template <bool STEM>
+__global__ __launch_bounds__(1024) void t_bn_bwd_finalize(const double* __restrict__ part, int R, float* __restrict__ gbn, float* __restrict__ sums)
+{
+    __shared__ double sh[1024];
+    const int c = threadIdx.x & 255, q = threadIdx.x >> 8;
+    if constexpr (!STEM) {
+        double s = 0.0, sx = 0.0;
+        for (int b = q; b < R; b += 4) { s += part[((size_t)b * 2 + 0) * NF + c]; sx += part[((size_t)b * 2 + 1) * NF + c]; }
+        s = reduce_q4(s, sh);
+        sx = reduce_q4(sx, sh);
+        if (q == 0) {
+            gbn[c] = (float)sx;
+            gbn[NF + c] = (float)s;
+            sums[c] = (float)s;
+            sums[NF + c] = (float)sx;
+        }
+    } else {
+        for (int g = 0; g < NG; g++) {
+            double s = 0.0, sx = 0.0;
+            for (int b = q; b < R; b += 4) {
+                s += part[((size_t)b * 2 * NG + g) * NF + c];
+                sx += part[((size_t)b * 2 * NG + NG + g) * NF + c];
+            }
+            s = block_sum_1024(s, sh);
+            sx = block_sum_1024(sx, sh);
+            if (threadIdx.x == 0) { gbn[g] = (float)sx; gbn[NG + g] = (float)s; sums[g] = (float)s; sums[NF + g] = (float)sx; }
+        }
+    }
+}
+
+// backward stage 3: dY = gamma * istd * (dz - sum(dz)/n - xhat * sum(dz xhat)/n); dZ (optional) = dz for the shortcut
+template <bool STEM>
+__global__ __launch_bounds__(256) void t_bn_bwd_apply(const float* __restrict__ dOut, const float* __restrict__ Apost,
+                                                      const float* __restrict__ Y, const float* __restrict__ mean,
+                                                      const float* __restrict__ istd, const float* __restrict__ bn,
+                                                      const float* __restrict__ sums, float inv_count, float* __restrict__ dY,
+                                                      float* __restrict__ dZ, int M)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * (NF / 4)) return;
+    const int r = (int)(i / (NF / 4)), c4 = (int)(i % (NF / 4)) * 4;
+    const float4 d4 = reinterpret_cast<const float4*>(dOut)[i], a4 = reinterpret_cast<const float4*>(Apost)[i],
+                 y4 = reinterpret_cast<const float4*>(Y)[i];
+    const float d[4] = {d4.x, d4.y, d4.z, d4.w}, a[4] = {a4.x, a4.y, a4.z, a4.w}, y[4] = {y4.x, y4.y, y4.z, y4.w};
+    float o[4], z[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int ch = STEM ? (r % NPOS) / 6 : c4 + j;
+        const float dz = a[j] > 0.0f ? d[j] : 0.0f;
+        const float xh = (y[j] - mean[ch]) * istd[ch];
+        z[j] = dz;
+        o[j] = bn[ch] * istd[ch] * (dz - sums[ch] * inv_count - xh * (sums[NF + ch] * inv_count));
+    }
+    reinterpret_cast<float4*>(dY)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if (dZ) reinterpret_cast<float4*>(dZ)[i] = make_float4(z[0], z[1], z[2], z[3]);
+}
+
+// =====================================================================================================================
+// heads (build_graph.py:76-98)
+// =====================================================================================================================
+// 1x1 convs: pv0[r] = { H[r] . pi_w[:,0], H[r] . pi_w[:,1], H[r] . v_w, 0 }; one wave per row
+__global__ __launch_bounds__(256) void t_head_conv(const float* __restrict__ H, const float* __restrict__ hp, float* __restrict__ pv0, int M)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= M) return;
+    const float4 h = reinterpret_cast<const float4*>(H)[(size_t)r * 64 + lane];
+    const float hv[4] = {h.x, h.y, h.z, h.w};
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int c = lane * 4 + j;
+        s0 += hv[j] * hp[H_PI_W + c * 2];
+        s1 += hv[j] * hp[H_PI_W + c * 2 + 1];
+        s2 += hv[j] * hp[H_V_W + c];
+    }
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane == 0) reinterpret_cast<float4*>(pv0)[r] = make_float4(s0, s1, s2, 0.0f);
+}
+
+// batch statistics of the 3 head channels (bn_pi x2, bn_v) + moving averages; single block of 1024 threads
+__global__ __launch_bounds__(1024) void t_head_bn_stats(const float* __restrict__ pv0, int M, float* __restrict__ hp, float* __restrict__ hstat /* mean[3] istd[3] */)
+{
+    __shared__ double sh[1024];
+    for (int ch = 0; ch < 3; ch++) {
+        double s = 0.0, ss = 0.0;
+        for (int r = threadIdx.x; r < M; r += 1024) { const double v = pv0[(size_t)r * 4 + ch]; s += v; ss += v * v; }
+        s = block_sum_1024(s, sh);
+        ss = block_sum_1024(ss, sh);
+        if (threadIdx.x == 0) {
+            const double n = M, mu = s / n, var = fmax(ss / n - mu * mu, 0.0);
+            hstat[ch] = (float)mu;
+            hstat[3 + ch] = (float)(1.0 / sqrt(var + (double)BN_EPS));
+            float* bn = ch < 2 ? hp + H_PI_BN : hp + H_V_BN;
+            const int C = ch < 2 ? 2 : 1, k = ch < 2 ? ch : 0;
+            bn[2 * C + k] = bn[2 * C + k] * BN_KEEP + (float)mu * (1.0f - BN_KEEP);
+            bn[3 * C + k] = bn[3 * C + k] * BN_KEEP + (float)(var * n / (n - 1.0)) * (1.0f - BN_KEEP);
+        }
+    }
+}
+
+__device__ __forceinline__ float head_bn_relu(const float* hp, const float* hstat, float x, int ch)
+{
+    const float* bn = ch < 2 ? hp + H_PI_BN : hp + H_V_BN;
+    const int C = ch < 2 ? 2 : 1, k = ch < 2 ? ch : 0;
+    const float v = bn[k] * ((x - hstat[ch]) * hstat[3 + ch]) + bn[C + k];
+    return v > 0.0f ? v : 0.0f;
+}
+
+// dense parts + losses; one block of 256 threads per board.  Saves fpi[84], fv[42], h1[256], v, prob[43].
+__global__ __launch_bounds__(256) void t_head_fwd(const float* __restrict__ pv0, const float* __restrict__ hp, const float* __restrict__ hstat,
+                                                  const float* __restrict__ pit, const float* __restrict__ zt, float* __restrict__ fpi,
+                                                  float* __restrict__ fv, float* __restrict__ h1, float* __restrict__ vout,
+                                                  float* __restrict__ prob, float* __restrict__ lossb)
+{
+    __shared__ float s_pi[84], s_v[42], s_h[256], s_l[44];
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t < 126) {
+        const int cell = t / 3, ch = t % 3;
+        const float f = head_bn_relu(hp, hstat, pv0[((size_t)b * NPOS + cell) * 4 + ch], ch);
+        if (ch < 2) { s_pi[cell * 2 + ch] = f; fpi[b * 84 + cell * 2 + ch] = f; }
+        else { s_v[cell] = f; fv[b * 42 + cell] = f; }
+    }
+    __syncthreads();
+    {   // dense_1 42 -> 256 + ReLU
+        float a = hp[H_V1_B + t];
+        for (int k = 0; k < 42; k++) a += s_v[k] * hp[H_V1_W + k * 256 + t];
+        a = a > 0.0f ? a : 0.0f;
+        s_h[t] = a;
+        h1[b * 256 + t] = a;
+    }
+    if (t < 43) {  // dense 84 -> 43
+        float a = hp[H_PD_B + t];
+        for (int k = 0; k < 84; k++) a += s_pi[k] * hp[H_PD_W + k * 43 + t];
+        s_l[t] = a;
+    }
+    __syncthreads();
+    if (t == 0) {
+        float mx = s_l[0];
+        for (int j = 1; j < 43; j++) mx = fmaxf(mx, s_l[j]);
+        float se = 0.0f;
+        for (int j = 0; j < 43; j++) se += expf(s_l[j] - mx);
+        const float lse = mx + logf(se);
+        float lp = 0.0f;
+        for (int j = 0; j < 43; j++) {
+            prob[b * 43 + j] = expf(s_l[j] - lse);
+            lp -= pit[b * 43 + j] * (s_l[j] - lse);
+        }
+        float a = hp[H_V2_B];
+        for (int j = 0; j < 256; j++) a += s_h[j] * hp[H_V2_W + j];
+        const float v = tanhf(a), dv = zt[b] - v;
+        vout[b] = v;
+        lossb[b * 2] = lp;
+        lossb[b * 2 + 1] = dv * dv;
+    }
+}
+
+// batch means of the two losses (softmax_cross_entropy / mean_squared_error reduce over the batch) -> loss[0..1];
+// acc[0..1] += them (the epoch sums of alphazero_nn.cpp:393-394, float like the reference)
+__global__ void t_loss(const float* __restrict__ lossb, int BS, float* __restrict__ loss, float* __restrict__ acc)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float lp = 0.0f, lv = 0.0f;
+    for (int b = 0; b < BS; b++) { lp += lossb[b * 2]; lv += lossb[b * 2 + 1]; }
+    lp /= (float)BS; lv /= (float)BS;
+    loss[0] = lp; loss[1] = lv;
+    acc[0] += lp; acc[1] += lv;
+}
+
+// backward of the dense parts; writes dz of the three head BN outputs (dpv [M][4]) and the per-board parameter partials
+__global__ __launch_bounds__(256) void t_head_bwd(const float* __restrict__ hp, const float* __restrict__ pit, const float* __restrict__ zt,
+                                                  const float* __restrict__ fpi, const float* __restrict__ fv, const float* __restrict__ h1,
+                                                  const float* __restrict__ vout, const float* __restrict__ prob, int BS,
+                                                  float* __restrict__ dpv, float* __restrict__ hpart)
+{
+    __shared__ float s_dl[43], s_dh[256], s_pi[84], s_v[42];
+    __shared__ float s_dv;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float inv = 1.0f / (float)BS;
+    float* hpb = hpart + (size_t)b * HP_FLOATS;
+    if (t < 84) s_pi[t] = fpi[b * 84 + t];
+    if (t < 42) s_v[t] = fv[b * 42 + t];
+    if (t == 0) {
+        float sp = 0.0f;
+        for (int j = 0; j < 43; j++) sp += pit[b * 43 + j];
+        for (int j = 0; j < 43; j++) s_dl[j] = (prob[b * 43 + j] * sp - pit[b * 43 + j]) * inv;
+        const float v = vout[b];
+        s_dv = 2.0f * (v - zt[b]) * inv * (1.0f - v * v);
+    }
+    __syncthreads();
+    const float dv = s_dv;
+    {
+        const float h = h1[b * 256 + t];
+        const float dh = h > 0.0f ? hp[H_V2_W + t] * dv : 0.0f;
+        s_dh[t] = dh;
+        hpb[HP_V1_B + t] = dh;
+        hpb[HP_V2_W + t] = h * dv;
+        if (t == 0) hpb[HP_V2_B] = dv;
+        if (t < 43) hpb[HP_PD_B + t] = s_dl[t];
+    }
+    __syncthreads();
+    for (int i = t; i < 84 * 43; i += 256) hpb[HP_PD_W + i] = s_pi[i / 43] * s_dl[i % 43];
+    for (int i = t; i < 42 * 256; i += 256) hpb[HP_V1_W + i] = s_v[i / 256] * s_dh[i % 256];
+    if (t < 84) {  // d fpi -> dz of bn_pi
+        float a = 0.0f;
+        for (int j = 0; j < 43; j++) a += hp[H_PD_W + t * 43 + j] * s_dl[j];
+        dpv[((size_t)b * NPOS + t / 2) * 4 + (t & 1)] = s_pi[t] > 0.0f ? a : 0.0f;
+    } else if (t >= 128 && t < 128 + 42) {  // d fv -> dz of bn_v
+        const int k = t - 128;
+        float a = 0.0f;
+        for (int j = 0; j < 256; j++) a += hp[H_V1_W + k * 256 + j] * s_dh[j];
+        dpv[((size_t)b * NPOS + k) * 4 + 2] = s_v[k] > 0.0f ? a : 0.0f;
+    }
+}
+
+// g[param] = sum over boards of the per-board partials
+__global__ void t_head_reduce(const float* __restrict__ hpart, int BS, float* __restrict__ ghead)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HP_FLOATS) return;
+    float s = 0.0f;
+    for (int b = 0; b < BS; b++) s += hpart[(size_t)b * HP_FLOATS + i];
+    int o;
+    if (i < HP_PD_B) o = H_PD_W + i;
+    else if (i < HP_V1_W) o = H_PD_B + (i - HP_PD_B);
+    else if (i < HP_V1_B) o = H_V1_W + (i - HP_V1_W);
+    else if (i < HP_V2_W) o = H_V1_B + (i - HP_V1_B);
+    else if (i < HP_V2_B) o = H_V2_W + (i - HP_V2_W);
+    else o = H_V2_B;
+    ghead[o] = s;
+}
+
+// BN backward of the 3 head channels in one block: dpv (dz) -> gradients of gamma/beta and dpv := d(conv output)
+__global__ __launch_bounds__(1024) void t_head_bn_bwd(const float* __restrict__ pv0, const float* __restrict__ hp, const float* __restrict__ hstat,
+                                                      int M, float* __restrict__ dpv, float* __restrict__ ghead)
+{
+    __shared__ double sh[1024];
+    for (int ch = 0; ch < 3; ch++) {
+        const float mu = hstat[ch], is = hstat[3 + ch];
+        double s = 0.0, sx = 0.0;
+        for (int r = threadIdx.x; r < M; r += 1024) {
+            const float dz = dpv[(size_t)r * 4 + ch];
+            s += dz;
+            sx += (double)dz * (double)((pv0[(size_t)r * 4 + ch] - mu) * is);
+        }
+        s = block_sum_1024(s, sh);
+        sx = block_sum_1024(sx, sh);
+        const int C = ch < 2 ? 2 : 1, k = ch < 2 ? ch : 0, base = ch < 2 ? H_PI_BN : H_V_BN;
+        if (threadIdx.x == 0) { ghead[base + k] = (float)sx; ghead[base + C + k] = (float)s; }
+        const float gamma = hp[base + k], fs = (float)s / (float)M, fsx = (float)sx / (float)M;
+        for (int r = threadIdx.x; r < M; r += 1024) {
+            const float dz = dpv[(size_t)r * 4 + ch];
+            const float xh = (pv0[(size_t)r * 4 + ch] - mu) * is;
+            dpv[(size_t)r * 4 + ch] = gamma * is * (dz - fs - xh * fsx);
+        }
+        __syncthreads();
+    }
+}
+
+// dH[r][c] = dp0 * pi_w[c][0] + dp1 * pi_w[c][1] + dv * v_w[c]; partial d(pi_w), d(v_w) per block of RB rows
+__global__ __launch_bounds__(256) void t_head_conv_bwd(const float* __restrict__ H, const float* __restrict__ dpv, const float* __restrict__ hp,
+                                                       int M, float* __restrict__ dH, float* __restrict__ part /* [R][3][256] */)
+{
+    const int c = threadIdx.x, r0 = blockIdx.x * RB, r1 = min(M, r0 + RB);
+    const float w0 = hp[H_PI_W + c * 2], w1 = hp[H_PI_W + c * 2 + 1], w2 = hp[H_V_W + c];
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    for (int r = r0; r < r1; r++) {
+        const float4 d = reinterpret_cast<const float4*>(dpv)[r];
+        const float h = H[(size_t)r * NF + c];
+        dH[(size_t)r * NF + c] = d.x * w0 + d.y * w1 + d.z * w2;
+        g0 += h * d.x; g1 += h * d.y; g2 += h * d.z;
+    }
+    part[((size_t)blockIdx.x * 3 + 0) * NF + c] = g0;
+    part[((size_t)blockIdx.x * 3 + 1) * NF + c] = g1;
+    part[((size_t)blockIdx.x * 3 + 2) * NF + c] = g2;
+}
+__global__ __launch_bounds__(256) void t_head_conv_bwd_finalize(const float* __restrict__ part, int R, float* __restrict__ ghead)
+{
+    const int c = threadIdx.x;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    for (int b = 0; b < R; b++) {
+        g0 += part[((size_t)b * 3 + 0) * NF + c];
+        g1 += part[((size_t)b * 3 + 1) * NF + c];
+        g2 += part[((size_t)b * 3 + 2) * NF + c];
+    }
+    ghead[H_PI_W + c * 2] = g0;
+    ghead[H_PI_W + c * 2 + 1] = g1;
+    ghead[H_V_W + c] = g2;
+}
+
+// =====================================================================================================================
+// Adam (tf.train.AdamOptimizer: lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t); w -= lr_t * m / (sqrt(v) + eps)); kind 1 adds
+// the L2 regulariser's gradient 2 * L2_C * w (keras l2 = l * sum w^2), kind 0 (BN moving statistics) is not trained
+// =====================================================================================================================
+__global__ void t_adam(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                       const uint8_t* __restrict__ kind, size_t n, float lr_t)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int k = kind[i];
+    if (k == 0) return;
+    float gi = g[i];
+    if (k == 1) gi += 2.0f * L2_C * w[i];
+    const float mi = ADAM_B1 * m[i] + (1.0f - ADAM_B1) * gi;
+    const float vi = ADAM_B2 * v[i] + (1.0f - ADAM_B2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    w[i] -= lr_t * mi / (sqrtf(vi) + ADAM_EPS);
+}
+
+// =====================================================================================================================
+// host
+// =====================================================================================================================
+struct TrainCtx {
+    int BS = 0, blocks = 0, M = 0, L = 0, R = 0, nz = 0, kchunk = 0;
+    size_t count = 0;
+    long step = 0;
+    float *g = nullptr, *m = nullptr, *v = nullptr;
+    uint8_t* kind = nullptr;
+    float *X0 = nullptr, *col0 = nullptr, *wpad = nullptr, *gpad = nullptr;
+    float *Y = nullptr, *A = nullptr;        // [L][M][256]
+    float *col = nullptr, *dcol = nullptr;   // [M][KC]
+    float *G = nullptr, *DS = nullptr, *DT = nullptr, *dY = nullptr;
+    float *mean = nullptr, *istd = nullptr;  // [L][256]
+    float* sums = nullptr;                   // [2][256]
+    double* part = nullptr;                  // [R][2*NG][256]
+    float* wpart = nullptr;                  // split-K partials [nz][KC][256]
+    float *pv0 = nullptr, *dpv = nullptr, *hstat = nullptr, *fpi = nullptr, *fv = nullptr, *h1 = nullptr, *vout = nullptr,
+          *prob = nullptr, *lossb = nullptr, *hpart = nullptr, *cpart = nullptr, *loss = nullptr;
+    uint8_t* rec = nullptr;
+    size_t rec_cap = 0;
+    int* perm = nullptr;
+    size_t perm_cap = 0;
+    uint8_t* in88 = nullptr;
+    float *pit = nullptr, *zt = nullptr;
+    std::vector<void*> allocs;
+};
+
+TrainCtx* ctx_of(azr_engine* h) { return static_cast<TrainCtx*>(h->train); }
+
+template <typename T>
+int dalloc(azr_engine* h, TrainCtx* c, T** p, size_t n)
+{
+    HIPCHK(h, hipMalloc((void**)p, n * sizeof(T)));
+    c->allocs.push_back(*p);
+    return AZR_OK;
+}
+
+void ctx_free(TrainCtx* c)
+{
+    if (!c) return;
+    for (void* p : c->allocs) hipFree(p);
+    if (c->rec) hipFree(c->rec);
+    if (c->perm) hipFree(c->perm);
+    delete c;
+}
+
+#define TRY(x)                 \
+    do {                       \
+        int rc__ = (x);        \
+        if (rc__) return rc__; \
+    } while (0)
+
+int ctx_ensure(azr_engine* h, int BS)
+{
+    TrainCtx* c = ctx_of(h);
+    if (c && c->BS == BS) return AZR_OK;
+    // a different batch size rebuilds the activation slabs but keeps the optimiser state
+    std::vector<float> keep_m, keep_v;
+    long keep_step = 0;
+    if (c) {
+        keep_m.resize(c->count); keep_v.resize(c->count);
+        HIPCHK(h, hipMemcpy(keep_m.data(), c->m, c->count * 4, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(keep_v.data(), c->v, c->count * 4, hipMemcpyDeviceToHost));
+        keep_step = c->step;
+        ctx_free(c);
+        h->train = nullptr;
+    }
+    c = new TrainCtx();
+    h->train = c;
+    const int B = h->net.blocks;
+    c->BS = BS; c->blocks = B; c->M = BS * NPOS; c->L = 2 * B + 1;
+    c->R = (c->M + RB - 1) / RB;
+    c->count = net_param_count(B);
+    c->nz = std::max(1, std::min(16, (c->M + 1023) / 1024));
+    c->kchunk = (((c->M + c->nz - 1) / c->nz) + GK - 1) / GK * GK;
+    c->step = keep_step;
+    const size_t M = c->M, act = M * NF;
+    TRY(dalloc(h, c, &c->g, c->count)); TRY(dalloc(h, c, &c->m, c->count)); TRY(dalloc(h, c, &c->v, c->count));
+    TRY(dalloc(h, c, &c->kind, c->count));
+    TRY(dalloc(h, c, &c->X0, M * SIN)); TRY(dalloc(h, c, &c->col0, M * KS));
+    TRY(dalloc(h, c, &c->wpad, (size_t)KS * NF)); TRY(dalloc(h, c, &c->gpad, (size_t)KS * NF));
+    TRY(dalloc(h, c, &c->Y, act * c->L)); TRY(dalloc(h, c, &c->A, act * c->L));
+    TRY(dalloc(h, c, &c->col, M * KC)); TRY(dalloc(h, c, &c->dcol, M * KC));
+    TRY(dalloc(h, c, &c->G, act)); TRY(dalloc(h, c, &c->DS, act)); TRY(dalloc(h, c, &c->DT, act)); TRY(dalloc(h, c, &c->dY, act));
+    TRY(dalloc(h, c, &c->mean, (size_t)c->L * NF)); TRY(dalloc(h, c, &c->istd, (size_t)c->L * NF));
+    TRY(dalloc(h, c, &c->sums, (size_t)2 * NF));
+    TRY(dalloc(h, c, &c->part, (size_t)c->R * 2 * NG * NF));
+    TRY(dalloc(h, c, &c->wpart, (size_t)c->nz * KC * NF));
+    TRY(dalloc(h, c, &c->pv0, M * 4)); TRY(dalloc(h, c, &c->dpv, M * 4)); TRY(dalloc(h, c, &c->hstat, (size_t)8));
+    TRY(dalloc(h, c, &c->fpi, (size_t)BS * 84)); TRY(dalloc(h, c, &c->fv, (size_t)BS * 42)); TRY(dalloc(h, c, &c->h1, (size_t)BS * 256));
+    TRY(dalloc(h, c, &c->vout, (size_t)BS)); TRY(dalloc(h, c, &c->prob, (size_t)BS * 43)); TRY(dalloc(h, c, &c->lossb, (size_t)BS * 2));
+    TRY(dalloc(h, c, &c->hpart, (size_t)BS * HP_FLOATS)); TRY(dalloc(h, c, &c->cpart, (size_t)c->R * 3 * NF));
+    TRY(dalloc(h, c, &c->loss, (size_t)4));
+    TRY(dalloc(h, c, &c->in88, (size_t)BS * 88)); TRY(dalloc(h, c, &c->pit, (size_t)BS * 43)); TRY(dalloc(h, c, &c->zt, (size_t)BS));
+    HIPCHK(h, hipMemset(c->dpv, 0, M * 4 * sizeof(float)));
+    HIPCHK(h, hipMemset(c->g, 0, c->count * 4));
+    if (keep_m.empty()) {
+        HIPCHK(h, hipMemset(c->m, 0, c->count * 4));
+        HIPCHK(h, hipMemset(c->v, 0, c->count * 4));
+    } else {
+        HIPCHK(h, hipMemcpy(c->m, keep_m.data(), c->count * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(c->v, keep_v.data(), c->count * 4, hipMemcpyHostToDevice));
+    }
+    // parameter kinds: 1 = kernel (L2-regularised), 2 = BN gamma/beta and dense biases, 0 = BN moving statistics
+    std::vector<uint8_t> kind(c->count, 0);
+    auto fill = [&](size_t off, size_t n, uint8_t k) { std::fill(kind.begin() + off, kind.begin() + off + n, k); };
+    fill(0, OFF_STEM_BN, 1);
+    fill(OFF_STEM_BN, 14, 2);
+    for (int l = 0; l < 2 * B; l++) {
+        const size_t o = OFF_BLOCK0 + (size_t)l * LAYER;
+        fill(o, (size_t)9 * NF * NF, 1);
+        fill(o + (size_t)9 * NF * NF, 2 * NF, 2);
+    }
+    const size_t hh = OFF_BLOCK0 + (size_t)2 * B * LAYER;
+    if (hh + HEAD_FLOATS != c->count) { h->err = "azr_nn_train: AZRW layout mismatch"; return AZR_E_STATE; }
+    fill(hh + H_PI_W, 512, 1); fill(hh + H_PI_BN, 4, 2);
+    fill(hh + H_PD_W, 3612, 1); fill(hh + H_PD_B, 43, 2);
+    fill(hh + H_V_W, 256, 1); fill(hh + H_V_BN, 2, 2);
+    fill(hh + H_V1_W, 10752, 1); fill(hh + H_V1_B, 256, 2);
+    fill(hh + H_V2_W, 256, 1); fill(hh + H_V2_B, 1, 2);
+    HIPCHK(h, hipMemcpy(c->kind, kind.data(), c->count, hipMemcpyHostToDevice));
+    return AZR_OK;
+}
+
+template <bool A_MCONTIG, bool B_KCONTIG>
+void gemm(hipStream_t st, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, int nz = 1,
+          int kchunk = 0, size_t strideCz = 0)
+{
+    if (nz == 1) kchunk = K;
+    hipLaunchKernelGGL((t_gemm<A_MCONTIG, B_KCONTIG>), dim3((N + GT - 1) / GT, (M + GT - 1) / GT, nz), dim3(256), 0, st, A, lda, B, ldb, C,
+                       ldc, M, N, K, kchunk, strideCz);
+}
+
+inline dim3 grid1(size_t n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+// one optimiser step on the minibatch already gathered into c->in88 / pit / zt
+int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
+{
+    hipStream_t st = h->stream;
+    const int M = c->M, B = c->blocks, R = c->R, BS = c->BS;
+    float* w = h->net.d_flat;
+    float* g = c->g;
+    const size_t act = (size_t)M * NF;
+    const size_t hh = OFF_BLOCK0 + (size_t)2 * B * LAYER;
+    float* hp = w + hh;
+    float* gh = g + hh;
+    auto Wl = [&](int l) { return w + OFF_BLOCK0 + (size_t)(l - 1) * LAYER; };       // conv layer l >= 1: kernel, then bn
+    auto Gl = [&](int l) { return g + OFF_BLOCK0 + (size_t)(l - 1) * LAYER; };
+    auto Yl = [&](int l) { return c->Y + act * l; };
+    auto Al = [&](int l) { return c->A + act * l; };
+    const unsigned g4 = (unsigned)((act / 4 + 255) / 256);
+
+    // ---------------- forward, training mode
+    hipLaunchKernelGGL(t_planes, grid1((size_t)M * SIN, 256), dim3(256), 0, st, c->in88, M, c->X0);
+    hipLaunchKernelGGL(t_stem_pad, grid1((size_t)KS * NF, 256), dim3(256), 0, st, w, c->wpad);
+    hipLaunchKernelGGL((t_im2col<SIN>), grid1((size_t)M * 9, 4), dim3(256), 0, st, c->X0, c->col0, M);
+    gemm<false, false>(st, c->col0, KS, c->wpad, NF, Yl(0), NF, M, NF, KS);
+    hipLaunchKernelGGL((t_bn_stats<true>), dim3(R), dim3(1024), 0, st, Yl(0), M, c->part);
+    hipLaunchKernelGGL((t_bn_finalize<true>), dim3(1), dim3(1024), 0, st, c->part, R, (double)BS * 6 * NF, c->mean, c->istd, w + OFF_STEM_BN);
+    hipLaunchKernelGGL((t_bn_apply<true>), dim3(g4), dim3(256), 0, st, Yl(0), c->mean, c->istd, w + OFF_STEM_BN, (const float*)nullptr, Al(0), M);
+    for (int l = 1; l < c->L; l++) {
+        float* bn = Wl(l) + (size_t)9 * NF * NF;
+        const float* S = (l % 2 == 0) ? Al(l - 2) : nullptr;  // second conv of a block adds the block input
+        hipLaunchKernelGGL((t_im2col<NF>), grid1((size_t)M * 9, 4), dim3(256), 0, st, Al(l - 1), c->col, M);
+        gemm<false, false>(st, c->col, KC, Wl(l), NF, Yl(l), NF, M, NF, KC);
+        hipLaunchKernelGGL((t_bn_stats<false>), dim3(R), dim3(1024), 0, st, Yl(l), M, c->part);
+        hipLaunchKernelGGL((t_bn_finalize<false>), dim3(1), dim3(1024), 0, st, c->part, R, (double)M, c->mean + l * NF, c->istd + l * NF, bn);
+        hipLaunchKernelGGL((t_bn_apply<false>), dim3(g4), dim3(256), 0, st, Yl(l), c->mean + l * NF, c->istd + l * NF, bn, S, Al(l), M);
+    }
+    const float* H = Al(c->L - 1);
+    hipLaunchKernelGGL(t_head_conv, grid1((size_t)M, 4), dim3(256), 0, st, H, hp, c->pv0, M);
+    hipLaunchKernelGGL(t_head_bn_stats, dim3(1), dim3(1024), 0, st, c->pv0, M, hp, c->hstat);
+    hipLaunchKernelGGL(t_head_fwd, dim3(BS), dim3(256), 0, st, c->pv0, hp, c->hstat, c->pit, c->zt, c->fpi, c->fv, c->h1, c->vout, c->prob, c->lossb);
+    hipLaunchKernelGGL(t_loss, dim3(1), dim3(1), 0, st, c->lossb, BS, c->loss, d_acc);
+
+    // ---------------- backward
+    hipLaunchKernelGGL(t_head_bwd, dim3(BS), dim3(256), 0, st, hp, c->pit, c->zt, c->fpi, c->fv, c->h1, c->vout, c->prob, BS, c->dpv, c->hpart);
+    hipLaunchKernelGGL(t_head_reduce, grid1(HP_FLOATS, 256), dim3(256), 0, st, c->hpart, BS, gh);
+    hipLaunchKernelGGL(t_head_bn_bwd, dim3(1), dim3(1024), 0, st, c->pv0, hp, c->hstat, M, c->dpv, gh);
+    hipLaunchKernelGGL(t_head_conv_bwd, dim3(R), dim3(256), 0, st, H, c->dpv, hp, M, c->G, c->cpart);
+    hipLaunchKernelGGL(t_head_conv_bwd_finalize, dim3(1), dim3(256), 0, st, c->cpart, R, gh);
+    const float invM = 1.0f / (float)M;
+    const size_t wn = (size_t)KC * NF;
+    for (int l = c->L - 1; l >= 1; l--) {
+        // gradient w.r.t. this layer's post-activation output: G for the second conv of a block, DT for the first
+        const bool second = (l % 2 == 0);
+        const float* dOut = second ? c->G : c->DT;
+        float* bn = Wl(l) + wn;
+        float* gbn = Gl(l) + wn;
+        hipLaunchKernelGGL((t_bn_bwd_stats<false>), dim3(R), dim3(1024), 0, st, dOut, Al(l), Yl(l), c->mean + l * NF, c->istd + l * NF, M, c->part);
+        hipLaunchKernelGGL((t_bn_bwd_finalize<false>), dim3(1), dim3(1024), 0, st, c->part, R, gbn, c->sums);
+        hipLaunchKernelGGL((t_bn_bwd_apply<false>), dim3(g4), dim3(256), 0, st, dOut, Al(l), Yl(l), c->mean + l * NF, c->istd + l * NF, bn, c->sums,
+                           invM, c->dY, second ? c->DS : (float*)nullptr, M);
+        // dW = col(input)^T x dY  (split-K over the M rows)
+        hipLaunchKernelGGL((t_im2col<NF>), grid1((size_t)M * 9, 4), dim3(256), 0, st, Al(l - 1), c->col, M);
+        gemm<true, false>(st, c->col, KC, c->dY, NF, c->wpart, NF, KC, NF, M, c->nz, c->kchunk, wn);
+        hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, c->nz, wn, Gl(l));
+        // d(input) = col2im(dY x W^T) (+ shortcut gradient when this is the first conv of the block)
+        gemm<false, true>(st, c->dY, NF, Wl(l), NF, c->dcol, KC, M, KC, NF);
+        hipLaunchKernelGGL(t_col2im, grid1((size_t)M, 4), dim3(256), 0, st, c->dcol, second ? (const float*)nullptr : c->DS, second ? c->DT : c->G, M);
+    }
+    {   // stem: parameters only
+        hipLaunchKernelGGL((t_bn_bwd_stats<true>), dim3(R), dim3(1024), 0, st, c->G, Al(0), Yl(0), c->mean, c->istd, M, c->part);
+        hipLaunchKernelGGL((t_bn_bwd_finalize<true>), dim3(1), dim3(1024), 0, st, c->part, R, g + OFF_STEM_BN, c->sums);
+        hipLaunchKernelGGL((t_bn_bwd_apply<true>), dim3(g4), dim3(256), 0, st, c->G, Al(0), Yl(0), c->mean, c->istd, w + OFF_STEM_BN, c->sums,
+                           1.0f / ((float)BS * 6 * NF), c->dY, (float*)nullptr, M);
+        gemm<true, false>(st, c->col0, KS, c->dY, NF, c->wpart, NF, KS, NF, M, c->nz, c->kchunk, (size_t)KS * NF);
+        hipLaunchKernelGGL(t_sum_slices, grid1((size_t)KS * NF, 256), dim3(256), 0, st, c->wpart, c->nz, (size_t)KS * NF, c->gpad);
+        hipLaunchKernelGGL(t_stem_unpad, grid1((size_t)9 * 13 * NF, 256), dim3(256), 0, st, c->gpad, g);
+    }
+    // ---------------- Adam
+    c->step++;
+    const double t = (double)c->step;
+    const float lr_t = (float)((double)LR * sqrt(1.0 - pow((double)ADAM_B2, t)) / (1.0 - pow((double)ADAM_B1, t)));
+    hipLaunchKernelGGL(t_adam, grid1(c->count, 256), dim3(256), 0, st, w, g, c->m, c->v, c->kind, c->count, lr_t);
+    HIPCHK(h, hipGetLastError());
+    return AZR_OK;
+}
+
+// after training: device master copy -> host AZRW copy -> refold / repack for inference
+int finish(azr_engine* h)
+{
+    HIPCHK(h, hipMemcpyAsync(h->flat.data(), h->net.d_flat, h->flat.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return net_upload(h);
+}
+
+int upload_records(azr_engine* h, TrainCtx* c, const void* rec, size_t n)
+{
+    if (n > c->rec_cap) {
+        if (c->rec) hipFree(c->rec);
+        c->rec = nullptr; c->rec_cap = 0;
+        HIPCHK(h, hipMalloc((void**)&c->rec, n * 265));
+        c->rec_cap = n;
+    }
+    if (n > c->perm_cap) {
+        if (c->perm) hipFree(c->perm);
+        c->perm = nullptr; c->perm_cap = 0;
+        HIPCHK(h, hipMalloc((void**)&c->perm, n * sizeof(int)));
+        c->perm_cap = n;
+    }
+    HIPCHK(h, hipMemcpyAsync(c->rec, rec, n * 265, hipMemcpyHostToDevice, h->stream));
+    return AZR_OK;
+}
+
+}  // namespace
+
+namespace azr {
+void train_free(azr_engine* h)
+{
+    ctx_free(ctx_of(h));
+    h->train = nullptr;
+}
+}  // namespace azr
+
+#define ENTER(h)                                 \
+    if (!(h)) return AZR_E_BAD_HANDLE;           \
+    HIPCHK(h, hipSetDevice((h)->cfg.device))
+
+extern "C" int azr_nn_train_batch(azr_engine* h, const void* rec265_host, int n, float* loss_pi, float* loss_v)
+{
+    ENTER(h);
+    if (!h->weights_set) { h->err = "azr_nn_train_batch: no weights"; return AZR_E_STATE; }
+    if (!rec265_host || n < 2) { h->err = "azr_nn_train_batch: need a minibatch of at least 2 records"; return AZR_E_INVALID_ARGUMENT; }
+    TRY(ctx_ensure(h, n));
+    TrainCtx* c = ctx_of(h);
+    TRY(upload_records(h, c, rec265_host, (size_t)n));
+    std::vector<int> id(n);
+    for (int i = 0; i < n; i++) id[i] = i;
+    HIPCHK(h, hipMemcpyAsync(c->perm, id.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(t_gather, dim3(n), dim3(64), 0, h->stream, c->rec, c->perm, n, c->in88, c->pit, c->zt);
+    HIPCHK(h, hipMemsetAsync(c->loss + 2, 0, 2 * sizeof(float), h->stream));
+    TRY(train_step(h, c, c->loss + 2));
+    float l[2];
+    HIPCHK(h, hipMemcpyAsync(l, c->loss, sizeof l, hipMemcpyDeviceToHost, h->stream));
+    TRY(finish(h));
+    if (loss_pi) *loss_pi = l[0];
+    if (loss_v) *loss_v = l[1];
+    return AZR_OK;
+}
+
+extern "C" int azr_nn_train(azr_engine* h, const void* rec265_host, size_t n, int epochs, int batch_size, uint32_t* shuffle_rng_state,
+                            float* loss_pi_host, float* loss_v_host)
+{
+    ENTER(h);
+    if (!h->weights_set) { h->err = "azr_nn_train: no weights"; return AZR_E_STATE; }
+    if (!rec265_host || epochs < 0 || batch_size < 2) { h->err = "azr_nn_train: bad arguments"; return AZR_E_INVALID_ARGUMENT; }
+    const size_t batches = n / (size_t)batch_size;  // the remainder of an epoch is dropped (alphazero_nn.cpp:374)
+    std::minstd_rand0 eng;                          // RNG.getEngine() (src/rng.h:5-50): the caller's stream continues here
+    if (shuffle_rng_state) {
+        // a raw engine state, as azr_engine_set_rng takes it; 0 is not a state of minstd_rand0
+        if (*shuffle_rng_state == 0 || *shuffle_rng_state >= 2147483647u) { h->err = "azr_nn_train: bad engine state"; return AZR_E_INVALID_ARGUMENT; }
+        eng.seed(*shuffle_rng_state);
+    }
+    std::vector<int> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = (int)i;
+    TrainCtx* c = nullptr;
+    if (batches > 0 && epochs > 0) {
+        TRY(ctx_ensure(h, batch_size));
+        c = ctx_of(h);
+        TRY(upload_records(h, c, rec265_host, n));
+    }
+    for (int e = 0; e < epochs; e++) {
+        std::shuffle(order.begin(), order.end(), eng);  // alphazero_nn.cpp:372 (same libstdc++ algorithm, same engine)
+        float l[2] = {NAN, NAN};
+        if (batches > 0) {
+            HIPCHK(h, hipMemcpyAsync(c->perm, order.data(), n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemsetAsync(c->loss + 2, 0, 2 * sizeof(float), h->stream));
+            for (size_t b = 0; b < batches; b++) {
+                hipLaunchKernelGGL(t_gather, dim3(batch_size), dim3(64), 0, h->stream, c->rec, c->perm + b * batch_size, batch_size, c->in88,
+                                   c->pit, c->zt);
+                TRY(train_step(h, c, c->loss + 2));
+            }
+            HIPCHK(h, hipMemcpyAsync(l, c->loss + 2, sizeof l, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            l[0] /= (float)batches;
+            l[1] /= (float)batches;
+        }
+        if (loss_pi_host) loss_pi_host[e] = l[0];
+        if (loss_v_host) loss_v_host[e] = l[1];
+    }
+    if (shuffle_rng_state) {
+        // minstd_rand0 has no state accessor; operator<< prints the state as decimal text
+        std::ostringstream os;
+        os << eng;
+        *shuffle_rng_state = (uint32_t)std::stoul(os.str());
+    }
+    if (batches > 0 && epochs > 0) TRY(finish(h));
+    return AZR_OK;
+}
+
+extern "C" int azr_nn_train_grads(azr_engine* h, float* flat_host, size_t count)
+{
+    ENTER(h);
+    TrainCtx* c = ctx_of(h);
+    if (!c) { h->err = "azr_nn_train_grads: no training step has run"; return AZR_E_STATE; }
+    if (!flat_host || count != c->count) return AZR_E_INVALID_ARGUMENT;
+    HIPCHK(h, hipMemcpy(flat_host, c->g, count * sizeof(float), hipMemcpyDeviceToHost));
+    return AZR_OK;
+}
+
+extern "C" int azr_nn_train_reset(azr_engine* h)
+{
+    if (!h) return AZR_E_BAD_HANDLE;
+    azr::train_free(h);
+    return AZR_OK;
+}

@@ -206,6 +206,27 @@ void NNTrainDataStorage::trimOldExamples()
     }
 }
 
+void NNTrainDataStorage::updateValues(int gameStatus, int roundCount)
+{
+    (void)roundCount;  // ROUND_WEIGHTED_VALUE is not a default macro
+    for (size_t i = lastGameIndex; i < data.size(); i++)
+        data[i].out.value = gameStatus == State::DRAW ? 0.0f : data[i].playerIndex == gameStatus ? 1.0f : -1.0f;
+    lastGameIndex = data.size();
+}
+
+std::vector<uint8_t> NNTrainDataStorage::packed() const
+{
+    std::vector<uint8_t> buf(data.size() * AZR_RECORD_BYTES);
+    for (size_t i = 0; i < data.size(); i++) {
+        uint8_t* r = buf.data() + i * AZR_RECORD_BYTES;
+        r[0] = (uint8_t)data[i].playerIndex;
+        memcpy(r + 1, data[i].in.bytes, AZR_INPUT_BYTES);
+        memcpy(r + 89, &data[i].out.value, 4);
+        memcpy(r + 93, data[i].out.policy.data(), 4 * AZR_MOVES);
+    }
+    return buf;
+}
+
 void NNTrainDataStorage::saveTrainingSamples(const std::string& path) const
 {
     if (data.empty()) { printf("No training samples\n"); return; }
@@ -301,6 +322,49 @@ std::vector<NNOutputData> AlphaZeroNNId::predict(const std::vector<NNInputData>&
     return out;
 }
 
+// stands in for the process-global RNG engine the reference shuffles with (src/rng.h:50); raw minstd_rand0 state
+static uint32_t g_shuffle_state = 1;
+static std::ofstream& logFile(const char* path)
+{
+    static std::map<std::string, std::ofstream> files;
+    auto& f = files[path];
+    if (!f.is_open()) { mkdirs("log"); f.open(path, std::ofstream::out | std::ofstream::app); }
+    return f;
+}
+
+void AlphaZeroNNId::train(const std::vector<NNTrainData>& trainData, int epochs)
+{
+    std::vector<uint8_t> buf(trainData.size() * AZR_RECORD_BYTES);
+    for (size_t i = 0; i < trainData.size(); i++) {
+        uint8_t* r = buf.data() + i * AZR_RECORD_BYTES;
+        r[0] = (uint8_t)trainData[i].playerIndex;
+        memcpy(r + 1, trainData[i].in.bytes, AZR_INPUT_BYTES);
+        memcpy(r + 89, &trainData[i].out.value, 4);
+        memcpy(r + 93, trainData[i].out.policy.data(), 4 * AZR_MOVES);
+    }
+    printf("Started training\n");
+    std::vector<float> lp(std::max(epochs, 1)), lv(std::max(epochs, 1));
+    auto t0 = std::chrono::steady_clock::now();
+    engine->check(azr_nn_train(engine->h, buf.data(), trainData.size(), epochs, SETTINGS.BATCH_SIZE, &g_shuffle_state, lp.data(), lv.data()),
+                  "train");
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int e = 0; e < epochs; e++) {
+        printf("EPOCH %d\nLoss Policy / Value: %f / %f\n", e, lp[e], lv[e]);
+        if (SETTINGS.LOG_NN_TRAINING) logFile("log/azr-nn-training-log.txt") << lp[e] << ", " << lv[e] << ", ";
+    }
+    if (SETTINGS.LOG_NN_TRAINING) logFile("log/azr-nn-training-log.txt") << std::endl;
+    const size_t steps = (size_t)epochs * (trainData.size() / SETTINGS.BATCH_SIZE);
+    printf("Trained %zu minibatch steps of %d in %.2f s (%.1f ms/step)\n", steps, SETTINGS.BATCH_SIZE, dt, steps ? 1e3 * dt / steps : 0.0);
+}
+
+void AlphaZeroNNGroup::train(const std::vector<NNTrainData>& trainData, int epochs)
+{
+    auto& nn = neuralNetworkIds.at(0);
+    nn->train(trainData, epochs);
+    nn->saveCheckpoint(SETTINGS.DEFAULT_CHECKPOINT_TEMP);
+    for (size_t i = 1; i < neuralNetworkIds.size(); i++) neuralNetworkIds[i]->loadCheckpoint(SETTINGS.DEFAULT_CHECKPOINT_TEMP);
+}
+
 std::shared_ptr<AlphaZeroNNGroup> AlphaZeroCluster::initPlayerGroup(const std::string& name, const std::string& graphPath)
 {
     for (auto& g : groups)
@@ -356,7 +420,7 @@ AlphaZeroPlayerGroup::AlphaZeroPlayerGroup(std::shared_ptr<AlphaZeroNNGroup> g) 
         for (int k = 0; k < SETTINGS.NUMBER_OF_CONCURENT_GAMES_PER_GPU; k++) players.push_back(std::make_shared<Player>());
 }
 
-void AlphaZeroPlayerGroup::takeTurns(int gpu, std::vector<State>& states, int8_t playerIndexTurn)
+void AlphaZeroPlayerGroup::takeTurns(int gpu, std::vector<State>& states, int8_t playerIndexTurn, std::vector<NNTrainDataStorage>* storages)
 {
     auto nn = nnGroup->getNN(gpu);
     Engine& e = *nn->engine;
@@ -377,6 +441,20 @@ void AlphaZeroPlayerGroup::takeTurns(int gpu, std::vector<State>& states, int8_t
         std::vector<uint8_t> mv = mcts.pickHigestWeightedMove();
         for (int g = 0; g < G; g++)
             if (!(status[g] == -1 && states[g].getCurrentPlayerTurn() == playerIndexTurn)) mv[g] = 255;
+        if (storages) {  // alphazero_player.cpp:15-18
+            std::vector<uint8_t> in88((size_t)G * AZR_INPUT_BYTES);
+            std::vector<float> pi((size_t)G * AZR_MOVES);
+            e.check(azr_engine_encode(e.h, in88.data()), "encode");
+            e.check(azr_mcts_policy(e.h, pi.data()), "policy");
+            for (int g = 0; g < G; g++) {
+                if (mv[g] == 255) continue;
+                NNTrainData d;
+                d.playerIndex = playerIndexTurn;
+                memcpy(d.in.bytes, in88.data() + (size_t)g * AZR_INPUT_BYTES, AZR_INPUT_BYTES);
+                d.out.policy.assign(pi.begin() + (size_t)g * AZR_MOVES, pi.begin() + (size_t)(g + 1) * AZR_MOVES);
+                (*storages)[g].data.push_back(std::move(d));
+            }
+        }
         e.check(azr_engine_make_moves(e.h, mv.data(), nullptr), "makeMove");
         e.check(azr_engine_get_states(e.h, img.data()), "get_states");
         for (int g = 0; g < G; g++) memcpy(states[g].data, img.data() + (size_t)g * AZR_STATE_BYTES, AZR_STATE_BYTES);
@@ -431,7 +509,6 @@ SelfPlayReport AlphaZeroTrainer::generateTrainData(std::shared_ptr<AlphaZeroNNGr
 
 void AlphaZeroTrainer::train(std::shared_ptr<AlphaZeroNNGroup> trainGroup, std::shared_ptr<AlphaZeroNNGroup> generateGroup)
 {
-    (void)trainGroup;
     trainStorage.loadTrainingSamples(SETTINGS.DEFAULT_SAMPLES);
     printf("Started training\n");
     for (trainIteration = 0; trainIteration < SETTINGS.TRAIN_ITERATIONS; trainIteration++) {
@@ -441,11 +518,206 @@ void AlphaZeroTrainer::train(std::shared_ptr<AlphaZeroNNGroup> trainGroup, std::
                (unsigned long long)r.games, (unsigned long long)r.decisions, (unsigned long long)r.simulations, r.seconds,
                r.simulations / r.seconds, r.games / r.seconds);
         trainStorage.trimOldExamples();
-        // trainGroup->train(...) + updateIfImprovement (alphazero_trainer.cpp:25-31) are SURVEY §8(f) "next" rows:
-        // the optimiser step and the arena are not built in this round, so the net stays at its checkpoint.
-        printf("[this round] train step / arena not built yet (SURVEY §8f-2): weights unchanged\n");
+        trainGroup->train(trainStorage.data, SETTINGS.EPOCHS);
+        if (updateIfImprovement(trainGroup, generateGroup, true)) trainStorage.updateOldGamesIndex();
     }
     trainStorage.saveTrainingSamples(SETTINGS.DEFAULT_SAMPLES);
+}
+
+// ---- game driver -----------------------------------------------------------------------------------------------------
+void GameResults::add(const GameResults& o)
+{
+    count += o.count; draw += o.draw;
+    for (int p = 0; p < 2; p++) { players[p].win += o.players[p].win; players[p].winAndStartedGame += o.players[p].winAndStartedGame; }
+}
+void GameResults::addGame(int gameStatus, int startingPlayer)  // game.cpp:193-213
+{
+    count++;
+    if (gameStatus == State::DRAW) { draw++; return; }
+    players[gameStatus].win++;
+    if (gameStatus == startingPlayer) players[gameStatus].winAndStartedGame++;
+}
+std::ostream& operator<<(std::ostream& os, const GameResults& gr)  // game.cpp:227-235
+{
+    return os << gr.draw << ", " << gr.players[0].win << "/" << gr.players[0].winAndStartedGame << ", " << gr.players[1].win << "/"
+              << gr.players[1].winAndStartedGame;
+}
+
+// State::invertPlayers (state.cpp:493-516) on the byte image: swap owners 0 <-> 1 and the two PlayerStatus blocks
+static void invertPlayers(State& s)
+{
+    for (int i = 0; i < 42; i++) {
+        const uint8_t la = s.data[i], owner = la >> 6;
+        if (owner < 2) s.data[i] = (uint8_t)((la & 63) | ((owner ^ 1) << 6));
+    }
+    uint8_t tmp[48];
+    memcpy(tmp, s.data + 48, 48);
+    memcpy(s.data + 48, s.data + 96, 48);
+    memcpy(s.data + 96, tmp, 48);
+}
+
+GameResults GameGroup::playGames(AlphaZeroPlayerGroup& pg1, AlphaZeroPlayerGroup& pg2, int games, NNTrainDataStorage* tds)
+{
+    const int P = (int)pg1.nnGroup->size();
+    printf("Playing games %d\n", games);
+    std::vector<GameResults> res(P);
+    const int G = pg1.nnGroup->getNN(0)->engine->games;
+    std::vector<std::vector<NNTrainDataStorage>> st1(P, std::vector<NNTrainDataStorage>(tds ? G : 0)), st2 = st1;
+    std::vector<std::thread> threads;
+    const int pairs = games / 2;  // Counter::hasNext(2) (game.cpp:241-253): whole pairs only
+    for (int i = 0; i < P; i++)
+        threads.emplace_back([&, i]() {
+            Engine& e1 = *pg1.nnGroup->getNN(i)->engine;
+            AlphaZeroMCTS m1(pg1.nnGroup->getNN(i)), m2(pg2.nnGroup->getNN(i));
+            int quota = pairs / P + (i < pairs % P ? 1 : 0);  // pairs for this GPU
+            uint32_t seed = SETTINGS.BASE_SEED + 7919u + (uint32_t)i * (1u << 24);
+            std::vector<uint8_t> img((size_t)G * AZR_STATE_BYTES);
+            std::vector<int8_t> status(G);
+            while (quota > 0) {
+                const int take = std::min(G, quota);  // slot k < take plays pair k; the other slots' games are not counted
+                quota -= take;
+                std::vector<uint32_t> seeds(G);
+                for (int g = 0; g < G; g++) seeds[g] = seed++;
+                e1.check(azr_engine_new_games(e1.h, seeds.data()), "new_games");
+                e1.check(azr_engine_get_states(e1.h, img.data()), "get_states");
+                std::vector<State> start(G);
+                for (int g = 0; g < G; g++) memcpy(start[g].data, img.data() + (size_t)g * AZR_STATE_BYTES, AZR_STATE_BYTES);
+                for (int playerStart = 0; playerStart < 2; playerStart++) {  // Game::newGame + incPlayerStart
+                    std::vector<State> states = start;
+                    if (playerStart == 1) {
+                        if (SETTINGS.MIRROR_GAMES) for (auto& s : states) invertPlayers(s);
+                        else {
+                            for (int g = 0; g < G; g++) seeds[g] = seed++;
+                            e1.check(azr_engine_new_games(e1.h, seeds.data()), "new_games");
+                            e1.check(azr_engine_get_states(e1.h, img.data()), "get_states");
+                            for (int g = 0; g < G; g++) memcpy(states[g].data, img.data() + (size_t)g * AZR_STATE_BYTES, AZR_STATE_BYTES);
+                        }
+                    }
+                    for (auto& s : states) s.data[146] = (uint8_t)playerStart;  // setCurrentPlayerTurn
+                    m1.clearNodes();  // AlphaZeroPlayer::newGame
+                    m2.clearNodes();
+                    for (;;) {        // Game::gameLoop
+                        pg1.takeTurns(i, states, 0, tds ? &st1[i] : nullptr);
+                        pg2.takeTurns(i, states, 1, tds ? &st2[i] : nullptr);
+                        for (int g = 0; g < G; g++) memcpy(img.data() + (size_t)g * AZR_STATE_BYTES, states[g].data, AZR_STATE_BYTES);
+                        e1.check(azr_engine_set_states(e1.h, img.data()), "set_states");
+                        e1.check(azr_engine_status(e1.h, status.data()), "status");
+                        bool running = false;
+                        for (int g = 0; g < G; g++) running |= status[g] == -1;
+                        if (!running) break;
+                    }
+                    for (int g = 0; g < G; g++) {
+                        if (tds) {  // gameFinished -> updateValues; uncounted slots drop their records
+                            if (g < take) { st1[i][g].updateValues(status[g], states[g].getRound()); st2[i][g].updateValues(status[g], states[g].getRound()); }
+                            else { st1[i][g].data.resize(st1[i][g].lastGameIndex); st2[i][g].data.resize(st2[i][g].lastGameIndex); }
+                        }
+                        if (g < take) res[i].addGame(status[g], playerStart);
+                    }
+                    if (i == 0) {
+                        printf("\r%d [Draw/P1,P2]: %d, %d/%d, %d/%d", res[i].count, res[i].draw, res[i].players[0].win,
+                               res[i].players[0].winAndStartedGame, res[i].players[1].win, res[i].players[1].winAndStartedGame);
+                        fflush(stdout);
+                    }
+                }
+            }
+        });
+    for (auto& t : threads) t.join();
+    printf("\n");
+    GameResults all;
+    for (auto& r : res) all.add(r);
+    if (tds) {
+        for (auto& per : st1) for (auto& s : per) tds->extend(s);
+        for (auto& per : st2) for (auto& s : per) tds->extend(s);
+    }
+    return all;
+}
+
+GameResults GameGroup::playGames(AlphaZeroPlayerGroup& pg1, int otherKind, int games)
+{
+    const int P = (int)pg1.nnGroup->size();
+    printf("Playing games %d\n", games);
+    std::vector<azr_game_results> res(P);
+    std::vector<std::thread> threads;
+    const int pairs = games / 2;
+    for (int i = 0; i < P; i++)
+        threads.emplace_back([&, i]() {
+            Engine& e = *pg1.nnGroup->getNN(i)->engine;
+            const int share = 2 * (pairs / P + (i < pairs % P ? 1 : 0));
+            memset(&res[i], 0, sizeof res[i]);
+            if (share == 0) return;
+            e.check(azr_arena_start(e.h, AZR_PLAYER_ALPHAZERO, otherKind, share, 0, SETTINGS.MIRROR_GAMES,
+                                    SETTINGS.BASE_SEED + 104729u + (uint32_t)i * (1u << 24)), "arena_start");
+            int fin = 0;
+            while (!fin) e.check(azr_arena_run(e.h, 4 * (SETTINGS.MCTS_SIMULATIONS + 2), &fin), "arena_run");
+            e.check(azr_arena_results(e.h, &res[i]), "arena_results");
+        });
+    for (auto& t : threads) t.join();
+    GameResults all;
+    for (auto& r : res) {
+        all.count += r.count; all.draw += r.draw;
+        for (int p = 0; p < 2; p++) { all.players[p].win += r.win[p]; all.players[p].winAndStartedGame += r.win_and_started[p]; }
+    }
+    return all;
+}
+
+// ---- trainer: model selection (alphazero_trainer.cpp:121-198) ----------------------------------------------------------
+void AlphaZeroTrainer::benchmark(AlphaZeroPlayerGroup& azpg)
+{
+    printf("Playing benchmark games with random\n");
+    GameResults rGR = GameGroup::playGames(azpg, AZR_PLAYER_RANDOM, SETTINGS.BENCHMARK_GAMES_RANDOM);
+    printf("Model benchmark games played: %d \t Model: %d/%d \t Random: %d/%d\n", rGR.count, rGR.players[0].win,
+           rGR.players[0].winAndStartedGame, rGR.players[1].win, rGR.players[1].winAndStartedGame);
+    printf("Playing benchmark games with script\n");
+    GameResults sGR = GameGroup::playGames(azpg, AZR_PLAYER_SCRIPT, SETTINGS.BENCHMARK_GAMES_SCRIPT);
+    printf("Model benchmark games played: %d \t Model: %d/%d \t Script: %d/%d\n", sGR.count, sGR.players[0].win,
+           sGR.players[0].winAndStartedGame, sGR.players[1].win, sGR.players[1].winAndStartedGame);
+    logFile("log/azr-benchmark-log.txt") << trainIteration << ',' << rGR << ", " << sGR << std::endl;
+}
+
+bool AlphaZeroTrainer::isModelImproved(const GameResults& gr)
+{
+    // int >= int * float: evaluated in float like the reference's expression (alphazero_trainer.cpp:197)
+    return (float)gr.players[0].win >= (float)(gr.players[0].win + gr.players[1].win) * SETTINGS.COMPARE_TRESHOLD;
+}
+
+bool AlphaZeroTrainer::updateIfImprovement(std::shared_ptr<AlphaZeroNNGroup> trainGroup, std::shared_ptr<AlphaZeroNNGroup> generateGroup,
+                                           bool doBenchmark)
+{
+    const std::string iterCkpt = SETTINGS.DEFAULT_CHECKPOINT_DIR + "/checkpoint-iter-" + std::to_string(trainIteration) + ".bin";
+    if (SETTINGS.COMPARE_GAMES > 0) {
+        const size_t samples = trainStorage.data.size();
+        AlphaZeroPlayerGroup trainAZPG(trainGroup), generateAZPG(generateGroup);
+        printf("Playing comparison games betweean new and old model\n");
+        GameResults gr;
+        if (SETTINGS.INCLUDE_COMPARE_GAMES_TRAIN_SAMPLES) {
+            gr = GameGroup::playGames(trainAZPG, generateAZPG, SETTINGS.COMPARE_GAMES, &trainStorage);
+            printf("New samples generated from compare games %d\n", int(trainStorage.data.size() - samples));
+        } else {
+            gr = GameGroup::playGames(trainAZPG, generateAZPG, SETTINGS.COMPARE_GAMES);
+        }
+        logFile("log/azr-improvement-log.txt") << trainIteration << ',' << gr << std::endl;
+        if (isModelImproved(gr)) {
+            printf("Model improved\n");
+            trainGroup->saveCheckpoint(SETTINGS.DEFAULT_BEST_CHECKPOINT);
+            trainGroup->saveCheckpoint(iterCkpt);
+            generateGroup->loadCheckpoint(SETTINGS.DEFAULT_BEST_CHECKPOINT);
+            if (doBenchmark) benchmark(generateAZPG);
+            return true;
+        }
+        printf("Model did not improve\n");
+        if (SETTINGS.TRAINING_REVERT_MODEL) {
+            printf("Model reverted back old\n");
+            trainGroup->loadCheckpoint(SETTINGS.DEFAULT_LATEST_CHECKPOINT);
+        }
+        return false;
+    }
+    printf("Model improved (No compare games set)\n");
+    trainGroup->saveCheckpoint(SETTINGS.DEFAULT_BEST_CHECKPOINT);
+    trainGroup->saveCheckpoint(iterCkpt);
+    generateGroup->loadCheckpoint(SETTINGS.DEFAULT_BEST_CHECKPOINT);
+    AlphaZeroPlayerGroup generateAZPG(generateGroup);
+    if (doBenchmark) benchmark(generateAZPG);
+    return true;
 }
 
 }  // namespace azrhost

@@ -113,6 +113,9 @@ public:
     void appendPacked(const uint8_t* rec265, size_t n);
     void extend(NNTrainDataStorage& s) { data.insert(data.end(), s.data.begin(), s.data.end()); }
     void trimOldExamples();  // alphazero_nn_data.cpp:67-84
+    void updateValues(int gameStatus, int roundCount);  // alphazero_nn_data.cpp:51-65 (roundCount unused by default)
+    void updateOldGamesIndex() { oldGameIndex = data.size() - 1; }  // alphazero_nn_data.cpp:160-163
+    std::vector<uint8_t> packed() const;                // 265-byte records, file order
     // writer = the reference's (8-byte size_t count); reader accepts that and the 4-byte count the reference's own
     // reader expects
     void saveTrainingSamples(const std::string& path) const;
@@ -140,6 +143,9 @@ public:
     void saveCheckpoint(const std::string& path);
     NNOutputData predict(const NNInputData& in);
     std::vector<NNOutputData> predict(const std::vector<NNInputData>& in);
+    // AlphaZeroNN::train (alphazero_nn.cpp:351-410) through azr_nn_train: EPOCH loop, shuffle, floor(n/BATCH_SIZE)
+    // optimiser steps, loss prints and log/azr-nn-training-log.txt columns
+    void train(const std::vector<NNTrainData>& trainData, int epochs);
 };
 
 class AlphaZeroNNGroup {  // alphazero_gpu_cluster.h:76-95: the same net on every GPU
@@ -150,6 +156,8 @@ public:
     std::shared_ptr<AlphaZeroNNId> getNN(int i) { return neuralNetworkIds.at(i); }
     void loadCheckpoint(const std::string& path) { for (auto& n : neuralNetworkIds) n->loadCheckpoint(path); }
     void saveCheckpoint(const std::string& path) { neuralNetworkIds.at(0)->saveCheckpoint(path); }
+    // alphazero_gpu_cluster.cpp:221-231: train on GPU 0's net, hand the weights to the others through temp.bin
+    void train(const std::vector<NNTrainData>& trainData, int epochs);
 };
 
 class AlphaZeroCluster {  // alphazero_gpu_cluster.h:97-111
@@ -202,7 +210,27 @@ public:
     explicit AlphaZeroPlayerGroup(std::shared_ptr<AlphaZeroNNGroup> g);
     size_t size() override { return players.size(); }
     std::shared_ptr<Player> getPlayer(int i) override { return players.at(i); }
-    void takeTurns(int gpu, std::vector<State>& states, int8_t playerIndexTurn);
+    // storages (optional, one per game slot): the records AlphaZeroPlayer::takeTurn pushes when trainStorage is set
+    void takeTurns(int gpu, std::vector<State>& states, int8_t playerIndexTurn, std::vector<NNTrainDataStorage>* storages = nullptr);
+};
+
+// game/game.h GameResults + operator<< (game.cpp:193-235)
+struct GameResults {
+    int count = 0, draw = 0;
+    struct { int win = 0, winAndStartedGame = 0; } players[2];
+    void add(const GameResults& o);
+    void addGame(int gameStatus, int startingPlayer);
+};
+std::ostream& operator<<(std::ostream& os, const GameResults& gr);
+
+// GameGroup::playGames (game.cpp:256-312).  AlphaZero vs AlphaZero (two nets = two engines per GPU) runs the G slots
+// of a GPU as G lock-stepped Game objects — mirrored pairs, alternating starts (game.cpp:153-191) — one host thread per
+// GPU; AlphaZero vs Script/Random runs on the device arena (azr_arena_*).  `tds` (optional) collects the (s, pi, z)
+// records both AlphaZero players push during the games (alphazero_player.cpp:15-18,24-29), storages in player order.
+class GameGroup {
+public:
+    static GameResults playGames(AlphaZeroPlayerGroup& pg1, AlphaZeroPlayerGroup& pg2, int games, NNTrainDataStorage* tds = nullptr);
+    static GameResults playGames(AlphaZeroPlayerGroup& pg1, int otherKind /* AZR_PLAYER_SCRIPT | RANDOM */, int games);
 };
 
 struct SelfPlayReport {
@@ -218,6 +246,9 @@ public:
     // device-resident self-play; the per-GPU storages are concatenated in GPU order
     SelfPlayReport generateTrainData(std::shared_ptr<AlphaZeroNNGroup> generate);
     void train(std::shared_ptr<AlphaZeroNNGroup> trainGroup, std::shared_ptr<AlphaZeroNNGroup> generateGroup);
+    bool updateIfImprovement(std::shared_ptr<AlphaZeroNNGroup> trainGroup, std::shared_ptr<AlphaZeroNNGroup> generateGroup, bool doBenchmark);
+    void benchmark(AlphaZeroPlayerGroup& azpg);
+    static bool isModelImproved(const GameResults& gr);
 };
 
 }  // namespace azrhost

@@ -11,10 +11,12 @@ static void executeTrain()
 {
     auto cluster = std::make_shared<AlphaZeroCluster>();
     cluster->initGpus(SETTINGS.NUMBER_OF_GPUS);
+    auto trainGroup = cluster->initPlayerGroup("az_train", SETTINGS.GRAPH_DEF_PB_1);
+    trainGroup->loadCheckpoint(SETTINGS.DEFAULT_LATEST_CHECKPOINT);
     auto generateGroup = cluster->initPlayerGroup("az_generate", SETTINGS.GRAPH_DEF_PB_1);
     generateGroup->loadCheckpoint(SETTINGS.DEFAULT_LATEST_CHECKPOINT);
     AlphaZeroTrainer trainer;
-    trainer.train(generateGroup, generateGroup);
+    trainer.train(trainGroup, generateGroup);
 }
 
 // `-m play` (src/alphazero_risk.cpp:4-47): GameGroup::playGames(group1, group2, COMPARE_GAMES) on the device arena.

@@ -2,7 +2,8 @@
 over the MI355X engine:
 
     self-play (device-resident, azr_selfplay_*)  ->  replay buffer (trimOldExamples, alphazero_nn_data.cpp:67-84)
-    ->  train step (train.py, provisional PyTorch-ROCm autograd)  ->  arena new-vs-old through the batched Player seam
+    ->  train step (azr_nn_train: the HIP optimiser step of csrc/azr_train.hip; `--trainer torch` selects the PyTorch
+        cross-check implementation in train.py)  ->  arena new-vs-old through the batched Player seam
     (two engines = two nets, one tree per player as in the reference)  ->  accept (>= COMPARE_TRESHOLD of decided games)
     / revert  ->  benchmark vs RandomPlayer(10) and ScriptPlayer(100) on the device arena
 with the reference's log files (log/azr-improvement-log.txt, azr-benchmark-log.txt, azr-nn-training-log.txt) and
@@ -134,7 +135,10 @@ def learn(a, log=print):
         else:
             e.init_random(20260002)
             e.save(latest)
-    trainer = train_mod.Trainer(a.blocks, new.get_weights(), device=f"cuda:{a.device}", batch_size=a.bs, seed=a.seed)
+    trainer = None
+    if a.trainer == "torch":
+        trainer = train_mod.Trainer(a.blocks, new.get_weights(), device=f"cuda:{a.device}", batch_size=a.bs, seed=a.seed)
+    shuffle_state = a.seed % 2147483646 + 1   # raw minstd_rand0 state standing in for the reference's global RNG
     records = np.zeros((0, 265), np.uint8)
     old_game_index = 0
     imp_log = open("log/azr-improvement-log.txt", "a")
@@ -160,10 +164,17 @@ def learn(a, log=print):
         records = np.concatenate([records, new_recs])
         records, old_game_index = trim_old_examples(records, old_game_index, a.s, 16384 * a.bs)
         # ---- trainGroup->train (alphazero_gpu_cluster.cpp:221-231)
-        hist = trainer.train(records, a.e, nn_log)
+        t0 = time.time()
+        if trainer is not None:
+            hist = trainer.train(records, a.e, nn_log)
+            new.set_weights(trainer.flat())
+        else:
+            hist, shuffle_state = new.train(records, a.e, batch_size=a.bs, rng_state=shuffle_state)
+            hist = [h for h in hist if not np.isnan(h[0])]
+            nn_log.write("".join(f"{lp}, {lv}, " for lp, lv in hist) + "\n"); nn_log.flush()
+        steps = a.e * (len(records) // a.bs)
         if hist:
-            log(f"Loss Policy / Value: {hist[-1][0]:f} / {hist[-1][1]:f}")
-        new.set_weights(trainer.flat())
+            log(f"Loss Policy / Value: {hist[-1][0]:f} / {hist[-1][1]:f}   [{steps} steps, {1e3 * (time.time() - t0) / max(steps, 1):.1f} ms/step]")
         # ---- updateIfImprovement (alphazero_trainer.cpp:134-190)
         improved = True
         gr = None
@@ -183,7 +194,8 @@ def learn(a, log=print):
         else:
             log("Model did not improve\nModel reverted back old")
             new.load(latest)
-            trainer.load_flat(new.get_weights())
+            if trainer is not None:
+                trainer.load_flat(new.get_weights())
         summary.append(dict(iteration=it, samples=len(records), losses=hist, arena=gr, improved=improved))
     # saveTrainingSamples (reference writer layout: 8-byte count + 265-byte records)
     os.makedirs("data", exist_ok=True)
@@ -209,6 +221,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20260001)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--trainer", default="native", choices=["native", "torch"])
     learn(ap.parse_args())
 
 

@@ -101,6 +101,20 @@ int azr_nn_load(azr_engine* h, const char* path);          /* loadCheckpoint (al
 int azr_nn_save(azr_engine* h, const char* path);          /* saveCheckpoint (alphazero_nn.cpp:206-214) */
 /* predict / processBatchPrediction (alphazero_nn.cpp:236-267,322-349): n inputs -> softmax pi[n][43], tanh v[n] */
 int azr_nn_predict(azr_engine* h, const void* in88_host, int n, float* pi_host, float* v_host);
+/* AlphaZeroNN::train (alphazero_nn.cpp:351-410) on n 265-byte records: per epoch shuffle (std::shuffle with a
+ * minstd_rand0 — *shuffle_rng_state is the raw engine state in and out, standing in for the process-global RNG,
+ * src/rng.h:50; NULL = default-seeded), floor(n / batch_size) minibatch steps of the `optimize` op (fp32 forward in
+ * training mode, loss, backward, Adam; python/src/build_graph.py:54-103), remainder dropped.  loss_*_host[e] = the
+ * epoch averages the reference prints and logs (NaN when n < batch_size).  Adam moments and step count persist on the
+ * handle across calls like the TF session's slots; inference weights are refolded / repacked before returning. */
+int azr_nn_train(azr_engine* h, const void* rec265_host, size_t n, int epochs, int batch_size,
+                 uint32_t* shuffle_rng_state, float* loss_pi_host, float* loss_v_host);
+/* one `session->Run(..., {optimize})` (alphazero_nn.cpp:389-391) on exactly n records in the given order */
+int azr_nn_train_batch(azr_engine* h, const void* rec265_host, int n, float* loss_pi, float* loss_v);
+/* diagnostics: gradient vector of the last step in AZRW layout (moving-statistics slots unused) */
+int azr_nn_train_grads(azr_engine* h, float* flat_host, size_t count);
+/* drop the optimiser state and the training buffers */
+int azr_nn_train_reset(azr_engine* h);
 
 /* ---- search: AlphaZeroMCTS / StateSimulationsStorage (alphazero_mcts.h:55-95) ---------------------------- */
 int azr_mcts_clear(azr_engine* h);   /* clearNodes (alphazero_mcts.cpp:223-227), all games */

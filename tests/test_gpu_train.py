@@ -1,0 +1,190 @@
+"""the native optimiser step (azr_nn_train*, csrc/azr_train.hip) against the same graph in PyTorch fp32 on
+the CPU (alphazero-risk_amd/train.py::AzrNet, itself checked against the oracle's forward pass in tests/test_train.py).
+"parity unpinned": the reference's step is a TensorFlow session (absent here); what is pinned is build_graph.py's
+arithmetic — losses, batch-statistics BN incl. the stem's axis-1 BN, gradients, L2, TF-formula Adam, moving averages —
+and the reference's epoch loop (libstdc++ std::shuffle on minstd_rand0, remainder dropped, epoch-average losses).
+Tolerances are stated per test; they cover fp32 summation-order differences only."""
+import importlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import azr_testlib as T
+from gpu_common import ROOT, pkg
+
+pytestmark = pytest.mark.gpu
+train = importlib.import_module("alphazero-risk_amd.train")
+
+
+def records(n, seed=0):
+    """synthetic (s, pi, z) records on real encoded positions: pi random over a random support, z in {-1, 0, 1}"""
+    g = np.load(os.path.join(T.GOLDEN, "encode.npz"))
+    x = g["in88"]
+    rng = np.random.default_rng(seed)
+    x = x[rng.integers(0, len(x), n)]
+    pi = rng.uniform(0.0, 1.0, (n, 43)).astype(np.float32) * (rng.uniform(0, 1, (n, 43)) < 0.3)
+    pi[:, 42] += 1e-3
+    pi = (pi / pi.sum(1, keepdims=True)).astype(np.float32)
+    z = rng.integers(-1, 2, n).astype(np.float32)
+    rec = np.zeros((n, 265), np.uint8)
+    rec[:, 0] = x[:, 42]
+    rec[:, 1:89] = x
+    rec[:, 89:93] = z.view(np.uint8).reshape(n, 4)
+    rec[:, 93:265] = pi.view(np.uint8).reshape(n, 172)
+    return rec
+
+
+def torch_step(blocks, flat, rec):
+    """loss, gradients (AZRW layout, without the L2 term) and post-step BN moving statistics from the PyTorch graph"""
+    net = train.AzrNet(blocks, flat).double()
+    net.train()
+    in88, pi, z = train.unpack_records(rec)
+    x = torch.from_numpy(train.planes_from_in88(in88)).double()
+    lp, lv, _ = net.losses(x, torch.from_numpy(pi).double(), torch.from_numpy(z).double())
+    (lp + lv).backward()
+    g = np.zeros(net.count, np.float64)
+    for name, off, shape in net.lay:
+        n = int(np.prod(shape))
+        if name.endswith("_bn"):
+            key = name[:-3]
+            c = shape[1]
+            g[off:off + c] = net.p[key + "_g"].grad.numpy()
+            g[off + c:off + 2 * c] = net.p[key + "_b"].grad.numpy()
+        else:
+            g[off:off + n] = net.p[name].grad.numpy().reshape(-1)
+    return float(lp.detach()), float(lv.detach()), g, net.to_flat()
+
+
+def kinds(blocks):
+    k = np.zeros(train.layout(blocks)[1], np.uint8)
+    for name, off, shape in train.layout(blocks)[0]:
+        n = int(np.prod(shape))
+        if name.endswith("_bn"):
+            k[off:off + 2 * shape[1]] = 2
+        elif name.endswith("_b"):
+            k[off:off + n] = 2
+        else:
+            k[off:off + n] = 1
+    return k
+
+
+def tf_adam(w, g, m, v, t, k):
+    """tf.train.AdamOptimizer update in fp32 on the trainable slots; kernels get the L2 gradient 2e-3 w"""
+    w, g, m, v = (a.astype(np.float32).copy() for a in (w, g, m, v))
+    g = np.where(k == 1, g + np.float32(2e-3) * w, g)
+    lr_t = np.float32(1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t))
+    tr = k > 0
+    m2 = np.float32(0.9) * m + np.float32(1 - 0.9) * g
+    v2 = np.float32(0.999) * v + np.float32(1 - 0.999) * g * g
+    w2 = w - lr_t * m2 / (np.sqrt(v2) + np.float32(1e-8))
+    return np.where(tr, w2, w), np.where(tr, m2, m), np.where(tr, v2, v)
+
+
+@pytest.mark.parametrize("blocks,bs", [(1, 16), (2, 64)])
+def test_step_matches_torch_graph(blocks, bs):
+    P = pkg()
+    flat = T.make_net_flat(blocks, seed=11, perturb_bn=True)
+    rec = records(bs, seed=blocks)
+    eng = P.Engine(8, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64)
+    eng.set_weights(flat)
+    lp, lv = eng.train_batch(rec)
+    g = eng.train_grads()
+    w1 = eng.get_weights()
+    rlp, rlv, rg, rflat = torch_step(blocks, flat, rec)
+    # losses: fp32 vs float64 reference
+    assert abs(lp - rlp) <= 2e-5 * max(1, abs(rlp)) and abs(lv - rlv) <= 2e-5, (lp, rlp, lv, rlv)
+    # gradients per tensor: max error relative to the tensor's largest gradient
+    k = kinds(blocks)
+    for name, off, shape in train.layout(blocks)[0]:
+        n = int(np.prod(shape)) if not name.endswith("_bn") else 2 * shape[1]
+        a, b = g[off:off + n].astype(np.float64), rg[off:off + n]
+        scale = max(np.abs(b).max(), 1e-6)
+        err = np.abs(a - b).max() / scale
+        assert err <= 2e-3, (name, err, scale)
+    # BN moving statistics after the step (momentum 0.99, unbiased variance)
+    mov = (k == 0)
+    assert np.allclose(w1[mov], rflat[mov], rtol=2e-5, atol=1e-6)
+    # Adam on the engine's own gradients reproduces the engine's weights (first step: m = v = 0)
+    w_ref, _, _ = tf_adam(flat, g, np.zeros_like(flat), np.zeros_like(flat), 1, k)
+    tr = k > 0
+    assert np.abs(w1[tr] - w_ref[tr]).max() <= 2e-7, np.abs(w1[tr] - w_ref[tr]).max()
+    # inference after training uses the updated weights (refold / repack happened)
+    x = rec[:8, 1:89].copy()
+    pi, v = eng.predict(x)
+    eng2 = P.Engine(8, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64)
+    eng2.set_weights(w1)
+    pi2, v2 = eng2.predict(x)
+    assert (pi.view(np.uint32) == pi2.view(np.uint32)).all() and (v == v2).all()
+    eng.close(); eng2.close()
+
+
+def test_steps_are_reproducible_and_adam_state_persists():
+    P = pkg()
+    blocks, bs = 1, 32
+    flat = T.make_net_flat(blocks, seed=3)
+    rec = records(3 * bs, seed=9)
+    k = kinds(blocks)
+    outs = []
+    for _ in range(2):
+        eng = P.Engine(8, blocks=blocks, sims=1, dtype=P.NET_BF16, node_capacity=64)
+        eng.set_weights(flat)
+        w, m, v = flat.copy(), np.zeros_like(flat), np.zeros_like(flat)
+        for t in range(3):
+            eng.train_batch(rec[t * bs:(t + 1) * bs])
+            g = eng.train_grads()
+            mov = eng.get_weights()
+            w, m, v = tf_adam(w, g, m, v, t + 1, k)
+            w[k == 0] = mov[k == 0]
+            assert np.abs(mov[k > 0] - w[k > 0]).max() <= 5e-7
+        outs.append(eng.get_weights())
+        eng.close()
+    assert (outs[0].view(np.uint32) == outs[1].view(np.uint32)).all()   # atomic-free reductions: bit-reproducible
+
+
+def test_epoch_loop_follows_reference_shuffle(tmp_path):
+    """azr_nn_train == the reference's loop: std::shuffle(minstd_rand0) per epoch, floor(n / bs) steps, remainder
+    dropped, epoch-average losses; checked against train_batch driven by libstdc++'s own std::shuffle"""
+    exe = str(tmp_path / "shuffle_probe")
+    subprocess.check_call(["g++", "-O1", "-o", exe, os.path.join(ROOT, "tests", "helpers", "shuffle_probe.cpp")])
+    P = pkg()
+    blocks, bs, n, epochs, state = 1, 16, 70, 2, 20260001
+    out = subprocess.check_output([exe, str(n), str(state), str(epochs)]).decode().split("\n")
+    perms = [np.array(out[e].split(), int) for e in range(epochs)]
+    end_state = int(out[epochs])
+    flat = T.make_net_flat(blocks, seed=4)
+    rec = records(n, seed=5)
+    a = P.Engine(8, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64)
+    a.set_weights(flat)
+    hist, st = a.train(rec, epochs, batch_size=bs, rng_state=state)
+    assert st == end_state
+    b = P.Engine(8, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64)
+    b.set_weights(flat)
+    for e in range(epochs):
+        lp = lv = np.float32(0)
+        for c in range(n // bs):
+            l = b.train_batch(rec[perms[e][c * bs:(c + 1) * bs]])
+            lp += np.float32(l[0]); lv += np.float32(l[1])
+        assert hist[e] == (float(lp / np.float32(n // bs)), float(lv / np.float32(n // bs)))
+    assert (a.get_weights().view(np.uint32) == b.get_weights().view(np.uint32)).all()
+    # fewer records than a batch: no step, NaN losses, weights untouched
+    w = a.get_weights()
+    hist, _ = a.train(rec[:bs - 1], 1, batch_size=bs, rng_state=1)
+    assert np.isnan(hist[0][0]) and (a.get_weights() == w).all()
+    a.close(); b.close()
+
+
+def test_training_reduces_loss_on_fixed_batch():
+    P = pkg()
+    blocks, bs = 2, 64
+    eng = P.Engine(8, blocks=blocks, sims=1, dtype=P.NET_BF16, node_capacity=64)
+    eng.init_random(5)
+    rec = records(bs, seed=1)
+    first = eng.train_batch(rec)
+    for _ in range(30):
+        last = eng.train_batch(rec)
+    # the policy targets are high-entropy random distributions, so CE has a floor near their entropy
+    assert last[0] < first[0] - 0.3 and last[1] < 0.6 * first[1], (first, last)
+    eng.close()

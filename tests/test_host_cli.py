@@ -47,10 +47,23 @@ def test_unknown_flag_is_an_error(exe, tmp_path):
 
 @pytest.mark.gpu
 def test_learn_mode_generates_reference_format_samples(exe, tmp_path):
-    r = subprocess.run([exe, "-m", "learn", "--mcts=8", "--gpu-games=16", "--blocks=1", "--ti=1", "--tg=6", "--dtype=bf16"],
-                       cwd=tmp_path, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr
+    """one full AlphaZeroTrainer::train iteration in the C++ host: self-play -> azr_nn_train -> arena new vs old (its
+    samples join the replay buffer) -> accept -> benchmark vs Random / Script, with the reference's files"""
+    r = subprocess.run([exe, "-m", "learn", "--mcts=8", "--gpu-games=16", "--blocks=1", "--ti=1", "--tg=6", "--dtype=bf16",
+                        "--bs=64", "-e", "2", "--cg=4", "--ct=0"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr + r.stdout[-2000:]
     assert "Generated" in r.stdout and "simulations/s" in r.stdout
+    assert "EPOCH 1" in r.stdout and "Loss Policy / Value:" in r.stdout
+    assert "New samples generated from compare games" in r.stdout and "Model improved" in r.stdout
+    assert "Model benchmark games played: 10" in r.stdout and "Model benchmark games played: 100" in r.stdout
+    for f in ("log/azr-improvement-log.txt", "log/azr-benchmark-log.txt", "log/azr-nn-training-log.txt",
+              "checkpoints/best-checkpoint.bin", "checkpoints/checkpoint-iter-0.bin", "checkpoints/temp.bin"):
+        assert os.path.getsize(tmp_path / f) > 0, f
+    imp = open(tmp_path / "log" / "azr-improvement-log.txt").read().strip().split(",")
+    assert imp[0] == "0" and len(imp) == 4
+    nnl = open(tmp_path / "log" / "azr-nn-training-log.txt").read().strip().rstrip(",").split(",")
+    assert len(nnl) == 4 and all(float(x) > 0 for x in nnl)          # 2 epochs x (policy, value)
     raw = open(tmp_path / "data" / "training_samples.bin", "rb").read()
     n = int(np.frombuffer(raw[:8], np.uint64)[0])
     assert n > 0 and len(raw) == 8 + n * 265                                  # alphazero_nn_data.cpp:123-130

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Time the native optimiser step (azr_nn_train) at the reference's training shape: BATCH_SIZE 512, B residual blocks.
+    python tools/train_bench.py [--blocks 20] [--bs 512] [--batches 8] [--epochs 2]
+Prints ms per minibatch step and the achieved fp32 FLOP rate (3 x forward FLOPs of the dense-padded GEMMs)."""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+P = importlib.import_module("alphazero-risk_amd")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--blocks", type=int, default=20)
+    ap.add_argument("--bs", type=int, default=512)
+    ap.add_argument("--batches", type=int, default=8)
+    ap.add_argument("--epochs", type=int, default=2)
+    a = ap.parse_args()
+    eng = P.Engine(64, blocks=a.blocks, sims=8, dtype=P.NET_BF16)
+    eng.init_random(1)
+    # records from real self-play positions
+    eng.selfplay_start(7)
+    recs = []
+    while sum(len(r) for r in recs) < a.bs * a.batches:
+        eng.selfplay_run(64)
+        recs.append(eng.drain())
+    rec = np.concatenate(recs)[:a.bs * a.batches]
+    eng.train(rec[:a.bs], 1, batch_size=a.bs, rng_state=1)   # allocate + warm up
+    t0 = time.time()
+    hist, _ = eng.train(rec, a.epochs, batch_size=a.bs, rng_state=1)
+    dt = time.time() - t0
+    steps = a.epochs * a.batches
+    M = a.bs * 42
+    flop = 3 * 2.0 * M * 256 * (9 * 16 + 2 * a.blocks * 9 * 256)
+    print(f"blocks={a.blocks} bs={a.bs}: {1e3 * dt / steps:.2f} ms/step, {flop * steps / dt / 1e12:.1f} TFLOP/s fp32 (dense-padded GEMM work), "
+          f"losses {hist}")
+
+
+if __name__ == "__main__":
+    main()
