@@ -136,7 +136,7 @@ def learn(a, log=print):
             e.init_random(20260002)
             e.save(latest)
     trainer = None
-    if a.trainer == "torch":
+    if getattr(a, "trainer", "native") == "torch":
         trainer = train_mod.Trainer(a.blocks, new.get_weights(), device=f"cuda:{a.device}", batch_size=a.bs, seed=a.seed)
     shuffle_state = a.seed % 2147483646 + 1   # raw minstd_rand0 state standing in for the reference's global RNG
     records = np.zeros((0, 265), np.uint8)

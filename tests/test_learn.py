@@ -54,13 +54,14 @@ def test_trim_and_acceptance_rules():
 
 
 @pytest.mark.gpu
-def test_one_learn_iteration_end_to_end(tmp_path):
+@pytest.mark.parametrize("trainer", ["native", "torch"])
+def test_one_learn_iteration_end_to_end(tmp_path, trainer):
     L = learn_mod()
     cwd = os.getcwd()
     os.chdir(tmp_path)
     try:
         a = argparse.Namespace(ti=1, tg=8, mcts=6, gpu_games=8, blocks=1, e=2, bs=64, cg=4, ct=0.0, s=1024 * 512,
-                               seed=77, dtype="bf16", device=0)
+                               seed=77, dtype="bf16", device=0, trainer=trainer)
         out = L.learn(a, log=lambda *_: None)
     finally:
         os.chdir(cwd)
