@@ -7,9 +7,10 @@
 //   reference's TF session.
 //
 // Data layout (all fp32, row-major): an activation is [M = batch * 42 rows][256 channels], row = board * 42 + y * 6 + x —
-// the inference kernels' row order.  A 3x3 SAME convolution is  im2col ([M][9 * Cin])  x  W ([9 * Cin][256], which is the
-// AZRW kernel [tap][ci][co] as it lies in the flat vector)  on the fp32 MFMA (v_mfma_f32_32x32x2_f32); its two
-// gradients are the same GEMM kernel with transposed operand access (dcol = dY x W^T, dW = col^T x dY, split-K).
+// the inference kernels' row order.  A 3x3 SAME convolution is the implicit GEMM  im2col(A) [M][9 * 256]  x  W [9 * 256][256]
+// (W = the AZRW kernel [tap][ci][co] as it lies in the flat vector) on the fp32 MFMA (v_mfma_f32_32x32x2_f32); the
+// im2col matrix is never materialised — the tile loader gathers the shifted rows.  Its two gradients are the same
+// kernel with other operand views: dW = im2col(A)^T x dY (split-K), dA = im2col-(dY) x W^T (negated taps).
 // Every conv output (pre-BN) and every post-activation is kept for the backward pass: 2 x 22 MB per layer at batch 512,
 // 1.8 GB for the 41 conv layers of B = 20 — sized for 288 GB of HBM, nothing is recomputed.
 // Reductions (BN statistics, bias / BN / head gradients, split-K) are two-stage and atomic-free: a step is
@@ -69,93 +70,134 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // =====================================================================================================================
 constexpr int GT = 128, GK = 16, GLD = GT + 4;
 
-template <bool MN_CONTIG>
-__device__ __forceinline__ void gt_load(const float* __restrict__ P, int ld, int mn0, int k0, int MN, int Kend, int t, float (&r)[8])
+// tile loaders: a [GK][T] tile (T = 128 or 64 along m|n), T * GK / 256 floats per thread.  MODE selects the operand view:
+//   0  plain matrix: element (mn, k) at P[k * ld + mn] (MN_CONTIG) or P[mn * ld + k]
+//   1  implicit im2col of an activation P [rows][256]: the matrix col[row][tap * 256 + c] = P[row + off(tap)][c] inside
+//      the board, 0 outside (never materialised); "row" is mn when !MN_CONTIG (forward A) and k when MN_CONTIG (col^T)
+//   2  the same with the tap offsets negated (the transposed convolution of the backward-data pass)
+//   3  conv kernel W [tap][ci][co] viewed as B[k = tap * 256 + co][n = ci] (backward-data), !MN_CONTIG only
+template <bool MN_CONTIG, int T, int MODE>
+__device__ __forceinline__ void gt_load(const float* __restrict__ P, int ld, int mn0, int k0, int MN, int Kend, int t, float (&r)[T / 16])
 {
-    if constexpr (MN_CONTIG) {  // storage [k][mn]
-        const int k = k0 + (t >> 4), mn = mn0 + (t & 15) * 8;
-        const float* p = P + (size_t)k * ld + mn;
-        if (k < Kend && mn + 7 < MN) {
-            const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-            r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
-        } else {
+    constexpr int V = T / 16;  // 8 or 4 floats per thread
+    constexpr int TPR = 16 / V;
+    const int mn = MN_CONTIG ? mn0 + (t & 15) * V : mn0 + t / TPR;
+    const int k = MN_CONTIG ? k0 + (t >> 4) : k0 + (t % TPR) * V;
+    const float* p;
+    bool ok;  // the whole run of V elements is inside the matrix (runs never straddle: all extents are multiples of V)
+    if constexpr (MODE == 1 || MODE == 2) {
+        const int row = MN_CONTIG ? k : mn, kk = MN_CONTIG ? mn : k;  // kk = tap * 256 + c
+        const int tap = kk >> 8, c = kk & 255;
+        int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        if (MODE == 2) { dy = -dy; dx = -dx; }
+        const int pos = row % NPOS, y = pos / 6 + dy, x = pos - (pos / 6) * 6 + dx;
+        ok = (MN_CONTIG ? (row < Kend && kk < MN) : (row < MN && kk < Kend)) && y >= 0 && y < 7 && x >= 0 && x < 6;
+        p = P + (size_t)(row + dy * 6 + dx) * NF + c;
 #pragma unroll
-            for (int j = 0; j < 8; j++) r[j] = (k < Kend && mn + j < MN) ? p[j] : 0.0f;
-        }
-    } else {  // storage [mn][k]
-        const int mn = mn0 + (t >> 1), k = k0 + (t & 1) * 8;
-        const float* p = P + (size_t)mn * ld + k;
-        if (mn < MN && k + 7 < Kend) {
-            const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-            r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
-        } else {
+        for (int j = 0; j < V; j++) r[j] = 0.0f;
+        if (ok) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) r[j] = (mn < MN && k + j < Kend) ? p[j] : 0.0f;
+            for (int q = 0; q < V / 4; q++) {
+                const float4 a = reinterpret_cast<const float4*>(p)[q];
+                r[4 * q] = a.x; r[4 * q + 1] = a.y; r[4 * q + 2] = a.z; r[4 * q + 3] = a.w;
+            }
         }
-    }
-}
-
-template <bool MN_CONTIG>
-__device__ __forceinline__ void gt_store(float* S, int t, const float (&r)[8])
-{
-    if constexpr (MN_CONTIG) {
-        float* p = S + (t >> 4) * GLD + (t & 15) * 8;
-        *reinterpret_cast<float4*>(p) = make_float4(r[0], r[1], r[2], r[3]);
-        *reinterpret_cast<float4*>(p + 4) = make_float4(r[4], r[5], r[6], r[7]);
+        return;
+    } else if constexpr (MODE == 3) {
+        static_assert(!MN_CONTIG, "weight-tap view is k-contiguous");
+        p = P + (size_t)(k >> 8) * (NF * NF) + (size_t)mn * NF + (k & 255);
+        ok = mn < MN && k + V - 1 < Kend;
+    } else if constexpr (MN_CONTIG) {
+        p = P + (size_t)k * ld + mn;
+        ok = k < Kend && mn + V - 1 < MN;
     } else {
-        float* p = S + ((t & 1) * 8) * GLD + (t >> 1);
+        p = P + (size_t)mn * ld + k;
+        ok = mn < MN && k + V - 1 < Kend;
+    }
+    if (ok) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) p[j * GLD] = r[j];
+        for (int q = 0; q < V / 4; q++) {
+            const float4 a = reinterpret_cast<const float4*>(p)[q];
+            r[4 * q] = a.x; r[4 * q + 1] = a.y; r[4 * q + 2] = a.z; r[4 * q + 3] = a.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            const bool in = MN_CONTIG ? (k < Kend && mn + j < MN) : (mn < MN && k + j < Kend);
+            r[j] = (MODE == 0 && in) ? p[j] : 0.0f;
+        }
     }
 }
 
-template <bool A_MCONTIG, bool B_KCONTIG>
+template <bool MN_CONTIG, int T>
+__device__ __forceinline__ void gt_store(float* S, int t, const float (&r)[T / 16])
+{
+    constexpr int V = T / 16, LD = T + 4;
+    if constexpr (MN_CONTIG) {
+        float* p = S + (t >> 4) * LD + (t & 15) * V;
+#pragma unroll
+        for (int q = 0; q < V / 4; q++) reinterpret_cast<float4*>(p)[q] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+    } else {
+        constexpr int TPR = 16 / V;
+        float* p = S + ((t % TPR) * V) * LD + t / TPR;
+#pragma unroll
+        for (int j = 0; j < V; j++) p[j * LD] = r[j];
+    }
+}
+
+// BM = 128: 4 waves as 2 x 2, each 64 x 64 (2 x 2 MFMA tiles); BM = 64: 2 x 2 waves, each 32 x 64 (1 x 2 tiles) — the
+// smaller tile is for launches whose 128-row grid would leave CUs with 1 vs 2 blocks (forward conv: 336 -> 672 blocks)
+template <bool A_MCONTIG, bool B_KCONTIG, int BM, int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void t_gemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                               float* __restrict__ C, int ldc, int M, int N, int K, int kchunk, size_t strideCz)
 {
-    __shared__ __attribute__((aligned(16))) float As[GK * GLD];
+    constexpr int MI = BM / 64, LDA = BM + 4;
+    __shared__ __attribute__((aligned(16))) float As[GK * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[GK * GLD];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * GT;
     const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < MI; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
-    float ra[8], rb[8];
-    gt_load<A_MCONTIG>(A, lda, m0, kbeg, M, kend, t, ra);
-    gt_load<!B_KCONTIG>(B, ldb, n0, kbeg, N, kend, t, rb);
+    float ra[BM / 16], rb[8];
+    gt_load<A_MCONTIG, BM, AMODE>(A, lda, m0, kbeg, M, kend, t, ra);
+    gt_load<!B_KCONTIG, GT, BMODE>(B, ldb, n0, kbeg, N, kend, t, rb);
     for (int k0 = kbeg; k0 < kend; k0 += GK) {
         __syncthreads();
-        gt_store<A_MCONTIG>(As, t, ra);
-        gt_store<!B_KCONTIG>(Bs, t, rb);
+        gt_store<A_MCONTIG, BM>(As, t, ra);
+        gt_store<!B_KCONTIG, GT>(Bs, t, rb);
         __syncthreads();
         if (k0 + GK < kend) {
-            gt_load<A_MCONTIG>(A, lda, m0, k0 + GK, M, kend, t, ra);
-            gt_load<!B_KCONTIG>(B, ldb, n0, k0 + GK, N, kend, t, rb);
+            gt_load<A_MCONTIG, BM, AMODE>(A, lda, m0, k0 + GK, M, kend, t, ra);
+            gt_load<!B_KCONTIG, GT, BMODE>(B, ldb, n0, k0 + GK, N, kend, t, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < GK / 2; kk++) {
             const int k = kk * 2 + (lane >> 5);
-            const float a0 = As[k * GLD + wm * 64 + (lane & 31)], a1 = As[k * GLD + wm * 64 + 32 + (lane & 31)];
+            float a[MI];
+#pragma unroll
+            for (int i = 0; i < MI; i++) a[i] = As[k * LDA + wm * (32 * MI) + i * 32 + (lane & 31)];
             const float b0 = Bs[k * GLD + wn * 64 + (lane & 31)], b1 = Bs[k * GLD + wn * 64 + 32 + (lane & 31)];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; i++) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b0, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b1, acc[i][1], 0, 0, 0);
+            }
         }
     }
     float* Cz = C + (size_t)blockIdx.z * strideCz;
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < MI; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const int row = m0 + wm * 64 + i * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+                const int row = m0 + wm * (32 * MI) + i * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
                 const int col = n0 + wn * 64 + j * 32 + (lane & 31);
                 if (row < M && col < N) Cz[(size_t)row * ldc + col] = acc[i][j][e];
             }
@@ -246,22 +288,15 @@ __global__ __launch_bounds__(256) void t_im2col(const float* __restrict__ A, flo
     for (int q = lane; q < C / 4; q += 64) dst[q] = ok ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// dA[r][c] = sum_tap dcol[r - off(tap)][tap][c] (+ dS[r][c]): the transpose of t_im2col<256>
-__global__ __launch_bounds__(256) void t_col2im(const float* __restrict__ dcol, const float* __restrict__ dS, float* __restrict__ dA, int M)
+// a += b
+__global__ __launch_bounds__(256) void t_add(float* __restrict__ a, const float* __restrict__ b, size_t n4)
 {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (r >= M) return;
-    const int pos = r % NPOS, y0 = pos / 6, x0 = pos % 6;
-    float4 acc = dS ? reinterpret_cast<const float4*>(dS)[(size_t)r * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int tap = 0; tap < 9; tap++) {
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1, y = y0 - dy, x = x0 - dx;
-        if (y >= 0 && y < 7 && x >= 0 && x < 6) {
-            const float4 v = reinterpret_cast<const float4*>(dcol)[((size_t)(r - dy * 6 - dx) * 9 + tap) * 64 + lane];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
-    }
-    reinterpret_cast<float4*>(dA)[(size_t)r * 64 + lane] = acc;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 x = reinterpret_cast<float4*>(a)[i];
+    const float4 y = reinterpret_cast<const float4*>(b)[i];
+    x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+    reinterpret_cast<float4*>(a)[i] = x;
 }
 
 // =====================================================================================================================
@@ -760,7 +795,6 @@ struct TrainCtx {
     uint8_t* kind = nullptr;
     float *X0 = nullptr, *col0 = nullptr, *wpad = nullptr, *gpad = nullptr;
     float *Y = nullptr, *A = nullptr;        // [L][M][256]
-    float *col = nullptr, *dcol = nullptr;   // [M][KC]
     float *G = nullptr, *DS = nullptr, *DT = nullptr, *dY = nullptr;
     float *mean = nullptr, *istd = nullptr;  // [L][256]
     float* sums = nullptr;                   // [2][256]
@@ -823,7 +857,8 @@ int ctx_ensure(azr_engine* h, int BS)
     c->BS = BS; c->blocks = B; c->M = BS * NPOS; c->L = 2 * B + 1;
     c->R = (c->M + RB - 1) / RB;
     c->count = net_param_count(B);
-    c->nz = std::max(1, std::min(16, (c->M + 1023) / 1024));
+    // split-K of the weight-gradient GEMM (36 output tiles of 128 x 128): as many slices as keep <= 2 blocks per CU
+    c->nz = std::max(1, std::min(512 / ((KC / GT) * (NF / GT)), (c->M + 1023) / 1024));
     c->kchunk = (((c->M + c->nz - 1) / c->nz) + GK - 1) / GK * GK;
     c->step = keep_step;
     const size_t M = c->M, act = M * NF;
@@ -832,7 +867,6 @@ int ctx_ensure(azr_engine* h, int BS)
     TRY(dalloc(h, c, &c->X0, M * SIN)); TRY(dalloc(h, c, &c->col0, M * KS));
     TRY(dalloc(h, c, &c->wpad, (size_t)KS * NF)); TRY(dalloc(h, c, &c->gpad, (size_t)KS * NF));
     TRY(dalloc(h, c, &c->Y, act * c->L)); TRY(dalloc(h, c, &c->A, act * c->L));
-    TRY(dalloc(h, c, &c->col, M * KC)); TRY(dalloc(h, c, &c->dcol, M * KC));
     TRY(dalloc(h, c, &c->G, act)); TRY(dalloc(h, c, &c->DS, act)); TRY(dalloc(h, c, &c->DT, act)); TRY(dalloc(h, c, &c->dY, act));
     TRY(dalloc(h, c, &c->mean, (size_t)c->L * NF)); TRY(dalloc(h, c, &c->istd, (size_t)c->L * NF));
     TRY(dalloc(h, c, &c->sums, (size_t)2 * NF));
@@ -874,13 +908,13 @@ int ctx_ensure(azr_engine* h, int BS)
     return AZR_OK;
 }
 
-template <bool A_MCONTIG, bool B_KCONTIG>
+template <bool A_MCONTIG, bool B_KCONTIG, int BM = 128, int AMODE = 0, int BMODE = 0>
 void gemm(hipStream_t st, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, int nz = 1,
           int kchunk = 0, size_t strideCz = 0)
 {
     if (nz == 1) kchunk = K;
-    hipLaunchKernelGGL((t_gemm<A_MCONTIG, B_KCONTIG>), dim3((N + GT - 1) / GT, (M + GT - 1) / GT, nz), dim3(256), 0, st, A, lda, B, ldb, C,
-                       ldc, M, N, K, kchunk, strideCz);
+    hipLaunchKernelGGL((t_gemm<A_MCONTIG, B_KCONTIG, BM, AMODE, BMODE>), dim3((N + GT - 1) / GT, (M + BM - 1) / BM, nz), dim3(256), 0, st, A, lda, B, ldb,
+                       C, ldc, M, N, K, kchunk, strideCz);
 }
 
 inline dim3 grid1(size_t n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
@@ -906,15 +940,14 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     hipLaunchKernelGGL(t_planes, grid1((size_t)M * SIN, 256), dim3(256), 0, st, c->in88, M, c->X0);
     hipLaunchKernelGGL(t_stem_pad, grid1((size_t)KS * NF, 256), dim3(256), 0, st, w, c->wpad);
     hipLaunchKernelGGL((t_im2col<SIN>), grid1((size_t)M * 9, 4), dim3(256), 0, st, c->X0, c->col0, M);
-    gemm<false, false>(st, c->col0, KS, c->wpad, NF, Yl(0), NF, M, NF, KS);
+    gemm<false, false, 64>(st, c->col0, KS, c->wpad, NF, Yl(0), NF, M, NF, KS);
     hipLaunchKernelGGL((t_bn_stats<true>), dim3(R), dim3(1024), 0, st, Yl(0), M, c->part);
     hipLaunchKernelGGL((t_bn_finalize<true>), dim3(1), dim3(1024), 0, st, c->part, R, (double)BS * 6 * NF, c->mean, c->istd, w + OFF_STEM_BN);
     hipLaunchKernelGGL((t_bn_apply<true>), dim3(g4), dim3(256), 0, st, Yl(0), c->mean, c->istd, w + OFF_STEM_BN, (const float*)nullptr, Al(0), M);
     for (int l = 1; l < c->L; l++) {
         float* bn = Wl(l) + (size_t)9 * NF * NF;
         const float* S = (l % 2 == 0) ? Al(l - 2) : nullptr;  // second conv of a block adds the block input
-        hipLaunchKernelGGL((t_im2col<NF>), grid1((size_t)M * 9, 4), dim3(256), 0, st, Al(l - 1), c->col, M);
-        gemm<false, false>(st, c->col, KC, Wl(l), NF, Yl(l), NF, M, NF, KC);
+        gemm<false, false, 64, 1, 0>(st, Al(l - 1), KC, Wl(l), NF, Yl(l), NF, M, NF, KC);  // conv = implicit im2col x W
         hipLaunchKernelGGL((t_bn_stats<false>), dim3(R), dim3(1024), 0, st, Yl(l), M, c->part);
         hipLaunchKernelGGL((t_bn_finalize<false>), dim3(1), dim3(1024), 0, st, c->part, R, (double)M, c->mean + l * NF, c->istd + l * NF, bn);
         hipLaunchKernelGGL((t_bn_apply<false>), dim3(g4), dim3(256), 0, st, Yl(l), c->mean + l * NF, c->istd + l * NF, bn, S, Al(l), M);
@@ -943,13 +976,13 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         hipLaunchKernelGGL((t_bn_bwd_finalize<false>), dim3(1), dim3(1024), 0, st, c->part, R, gbn, c->sums);
         hipLaunchKernelGGL((t_bn_bwd_apply<false>), dim3(g4), dim3(256), 0, st, dOut, Al(l), Yl(l), c->mean + l * NF, c->istd + l * NF, bn, c->sums,
                            invM, c->dY, second ? c->DS : (float*)nullptr, M);
-        // dW = col(input)^T x dY  (split-K over the M rows)
-        hipLaunchKernelGGL((t_im2col<NF>), grid1((size_t)M * 9, 4), dim3(256), 0, st, Al(l - 1), c->col, M);
-        gemm<true, false>(st, c->col, KC, c->dY, NF, c->wpart, NF, KC, NF, M, c->nz, c->kchunk, wn);
+        // dW = col(input)^T x dY  (implicit im2col, split-K over the M rows)
+        gemm<true, false, 128, 1, 0>(st, Al(l - 1), KC, c->dY, NF, c->wpart, NF, KC, NF, M, c->nz, c->kchunk, wn);
         hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, c->nz, wn, Gl(l));
-        // d(input) = col2im(dY x W^T) (+ shortcut gradient when this is the first conv of the block)
-        gemm<false, true>(st, c->dY, NF, Wl(l), NF, c->dcol, KC, M, KC, NF);
-        hipLaunchKernelGGL(t_col2im, grid1((size_t)M, 4), dim3(256), 0, st, c->dcol, second ? (const float*)nullptr : c->DS, second ? c->DT : c->G, M);
+        // d(input) = transposed conv of dY with W: the same implicit GEMM with negated taps and W read as [tap][co] x [ci]
+        float* dIn = second ? c->DT : c->G;
+        gemm<false, true, 64, 2, 3>(st, c->dY, KC, Wl(l), NF, dIn, NF, M, NF, KC);
+        if (!second) hipLaunchKernelGGL(t_add, dim3(g4), dim3(256), 0, st, dIn, c->DS, act / 4);  // + shortcut gradient
     }
     {   // stem: parameters only
         hipLaunchKernelGGL((t_bn_bwd_stats<true>), dim3(R), dim3(1024), 0, st, c->G, Al(0), Yl(0), c->mean, c->istd, M, c->part);
