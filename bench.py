@@ -180,8 +180,8 @@ def main():
                          "flop_per_launch": a.games * fps, "avg_launch_ms": prof["net_ms"],
                          "tree_step_avg_ms": prof["tree_ms"], "timed_launches": prof["launches"],
                          # HBM-side bytes per launch from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction),
-                         # profiles/r01_pmc_fetch_write_g256_s100_b20.txt — measured for exactly this configuration
-                         "traffic": (2 * 186129.7 + 5376.0) * 1024
+                         # profiles/r01_final_pmc_fetch_write_g256_s100_b20.txt — measured for exactly this configuration
+                         "traffic": (2 * 186413.07 + 56.0) * 1024
                          if (a.games, a.blocks, a.dtype) == (256, 20, "bf16") else None},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -21,7 +21,11 @@ def main():
     ap.add_argument("--bs", type=int, default=512)
     ap.add_argument("--batches", type=int, default=8)
     ap.add_argument("--epochs", type=int, default=2)
+    ap.add_argument("--torch", action="store_true", help="also time the PyTorch-ROCm autograd implementation (train.py)")
     a = ap.parse_args()
+    if a.torch:   # torch bundles its own HIP runtime: let it initialise the device before the C-ABI library does
+        import torch
+        torch.cuda.init()
     eng = P.Engine(64, blocks=a.blocks, sims=8, dtype=P.NET_BF16)
     eng.init_random(1)
     # records from real self-play positions
@@ -40,6 +44,20 @@ def main():
     flop = 3 * 2.0 * M * 256 * (9 * 16 + 2 * a.blocks * 9 * 256)
     print(f"blocks={a.blocks} bs={a.bs}: {1e3 * dt / steps:.2f} ms/step, {flop * steps / dt / 1e12:.1f} TFLOP/s fp32 (dense-padded GEMM work), "
           f"losses {hist}")
+    if a.torch:
+        print(f"PyTorch-ROCm autograd (MIOpen fp32), same graph and batch: {1e3 * torch_time(a, eng, rec):.2f} ms/step")
+
+
+def torch_time(a, eng, rec):
+    import torch
+    T = importlib.import_module("alphazero-risk_amd.train")
+    tr = T.Trainer(a.blocks, eng.get_weights(), device="cuda:0", batch_size=a.bs, seed=0)
+    tr.train(rec[:a.bs], 1)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    tr.train(rec, a.epochs)
+    torch.cuda.synchronize()
+    return (time.time() - t0) / (a.epochs * a.batches)
 
 
 if __name__ == "__main__":
