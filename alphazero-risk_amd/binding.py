@@ -20,7 +20,7 @@ class AzrError(RuntimeError):
 class Settings(C.Structure):
     """`azr_settings` — mirrors the reference's `class Settings` fields the hot path reads (src/settings.h:41-64)."""
     _fields_ = [("device", C.c_int32), ("games", C.c_int32), ("blocks", C.c_int32), ("net_dtype", C.c_int32),
-                ("mcts_simulations", C.c_int32), ("allow_yield", C.c_int32), ("limit_reinforcement", C.c_int32),
+                ("mcts_simulations", C.c_int32), ("mcts_threads", C.c_int32), ("allow_yield", C.c_int32), ("limit_reinforcement", C.c_int32),
                 ("limit_attack", C.c_int32), ("max_game_rounds", C.c_int32), ("min_unit_move", C.c_int32),
                 ("temperature_threshold", C.c_int32), ("hp_exploration", C.c_float), ("dir_noise_value", C.c_float),
                 ("dir_noise_epsi", C.c_float), ("node_capacity", C.c_int32), ("sample_capacity", C.c_int32)]
@@ -130,11 +130,16 @@ class Engine:
     """One handle = one GPU = G concurrent games.  Method names follow the reference seams:
     State / UtilityNN (rules), AlphaZeroNNId (net), AlphaZeroMCTS (search), trainer move loop (self-play)."""
 
-    def __init__(self, games, blocks=20, sims=32, dtype=NET_BF16, device=0, **kw):
+    def __init__(self, games, blocks=20, sims=32, dtype=NET_BF16, device=0, threads=1, **kw):
+        """threads = THREADS_PER_MCTS.  The C default (azr_default_settings) is the reference's 2; this binding defaults
+        to 1, the only value at which the reference's search is deterministic and the parity tests are bit-exact
+        against `-t 1` semantics; tests of the T-thread schedule pass it explicitly."""
         self.L = load_library()
         s = Settings()
         self.L.azr_default_settings(C.byref(s))
         s.device, s.games, s.blocks, s.mcts_simulations, s.net_dtype = device, games, blocks, sims, dtype
+        s.mcts_threads = threads
+        self.T = threads
         for k, v in kw.items():
             if not hasattr(s, k):
                 raise TypeError(f"unknown setting {k}")
@@ -284,8 +289,8 @@ class Engine:
         self._chk(self.L.azr_mcts_begin(self.h))
 
     def mcts_leaves(self):
-        x = np.zeros((self.G, 88), np.uint8)
-        need = np.zeros(self.G, np.uint8)
+        x = np.zeros((self.G * self.T, 88), np.uint8)      # slot = g * T + k
+        need = np.zeros(self.G * self.T, np.uint8)
         act = C.c_int(0)
         self._chk(self.L.azr_mcts_leaves(self.h, _p(x), _p(need), C.byref(act)))
         return x, need.astype(bool), act.value
@@ -293,7 +298,7 @@ class Engine:
     def mcts_apply(self, pi, v):
         pi = np.ascontiguousarray(pi, np.float32)
         v = np.ascontiguousarray(v, np.float32)
-        assert pi.shape == (self.G, 43) and v.shape == (self.G,)
+        assert pi.shape == (self.G * self.T, 43) and v.shape == (self.G * self.T,)
         self._chk(self.L.azr_mcts_apply(self.h, _p(pi), _p(v)))
 
     def root_stats(self):

@@ -32,7 +32,7 @@ __device__ __forceinline__ Tree tree_of(const Dev& E, int g)
     t.nhash = E.nhash + (size_t)g * E.C;
     t.table = E.table + (size_t)g * E.H;
     t.freel = E.freel + (size_t)g * E.C;
-    t.path = E.path + (size_t)g * E.DMAX;
+    t.path = E.path + (size_t)g * E.T * E.DMAX;  // thread 0's stack; thread_tree() selects thread k's
     return t;
 }
 
@@ -41,23 +41,47 @@ __device__ __forceinline__ void ctl_load(Ctl& c, const Ctl* src)
     const uint32_t* p = reinterpret_cast<const uint32_t*>(src);
     uint32_t w = p[lane_id() & 31u];
     c.mode = rdl(w, 0); c.search_id = rdl(w, 1); c.sims_done = rdl(w, 2); c.pending = rdl(w, 3);
-    c.path_len = rdl(w, 4); c.nfree = rdl(w, 5); c.hiwater = rdl(w, 6); c.search_done = rdl(w, 7);
+    c.sims_started = rdl(w, 4); c.nfree = rdl(w, 5); c.hiwater = rdl(w, 6); c.search_done = rdl(w, 7);
     c.rng = rdl(w, 8); c.game_no = rdl(w, 9); c.nsamples = rdl(w, 10); c.status = (int32_t)rdl(w, 11);
     c.error = rdl(w, 12); c.last_move = rdl(w, 13); c.decisions = rdl(w, 14); c.seed = rdl(w, 15);
     c.arena_state = rdl(w, 16); c.player_start = rdl(w, 17); c.pair_phase = rdl(w, 18); c.turn_started = rdl(w, 19);
-    c.search_active = rdl(w, 20); c.slot_games = rdl(w, 21);
+    c.search_active = rdl(w, 20); c.slot_games = rdl(w, 21); c.dup_dropped = rdl(w, 22);
+#pragma unroll
+    for (int k = 0; k < MAX_THREADS; k++) c.plen[k] = rdl(w, 23 + k);
+}
+// c.plen[k] with a wave-uniform runtime k, without indexing the register array
+__device__ __forceinline__ uint32_t plen_get(const Ctl& c, int k)
+{
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < MAX_THREADS; i++) v = k == i ? c.plen[i] : v;
+    return v;
+}
+__device__ __forceinline__ void plen_set(Ctl& c, int k, uint32_t v)
+{
+#pragma unroll
+    for (int i = 0; i < MAX_THREADS; i++) c.plen[i] = k == i ? v : c.plen[i];
+}
+__device__ __forceinline__ Tree thread_tree(const Tree& t, int k)
+{
+    Tree tk = t;
+    tk.path = t.path + (size_t)k * t.DMAX;
+    return tk;
 }
 __device__ __forceinline__ void ctl_store(const Ctl& c, Ctl* dst)
 {
     uint32_t l = lane_id();
     uint32_t w = 0;
     w = l == 0 ? c.mode : w; w = l == 1 ? c.search_id : w; w = l == 2 ? c.sims_done : w; w = l == 3 ? c.pending : w;
-    w = l == 4 ? c.path_len : w; w = l == 5 ? c.nfree : w; w = l == 6 ? c.hiwater : w; w = l == 7 ? c.search_done : w;
+    w = l == 4 ? c.sims_started : w; w = l == 5 ? c.nfree : w; w = l == 6 ? c.hiwater : w; w = l == 7 ? c.search_done : w;
     w = l == 8 ? c.rng : w; w = l == 9 ? c.game_no : w; w = l == 10 ? c.nsamples : w; w = l == 11 ? (uint32_t)c.status : w;
     w = l == 12 ? c.error : w; w = l == 13 ? c.last_move : w; w = l == 14 ? c.decisions : w; w = l == 15 ? c.seed : w;
     w = l == 16 ? c.arena_state : w; w = l == 17 ? c.player_start : w; w = l == 18 ? c.pair_phase : w;
     w = l == 19 ? c.turn_started : w; w = l == 20 ? c.search_active : w; w = l == 21 ? c.slot_games : w;
-    if (l < 22) reinterpret_cast<uint32_t*>(dst)[l] = w;
+    w = l == 22 ? c.dup_dropped : w;
+#pragma unroll
+    for (int k = 0; k < MAX_THREADS; k++) w = l == 23u + k ? c.plen[k] : w;
+    if (l < 23 + MAX_THREADS) reinterpret_cast<uint32_t*>(dst)[l] = w;
 }
 
 // ================================================================================================
@@ -185,7 +209,7 @@ __global__ __launch_bounds__(64) void k_tree_clear(Dev E)
     // hiwater may be stale at creation: clear everything the pool can hold
     c.hiwater = (uint32_t)E.C;
     tree_clear(t, c);
-    c.pending = 0; c.path_len = 0; c.sims_done = 0; c.search_done = 1;
+    c.pending = 0; c.sims_started = 0; c.sims_done = 0; c.search_done = 1;
     ctl_store(c, &E.ctl[g]);
 }
 
@@ -210,7 +234,7 @@ __global__ __launch_bounds__(64) void k_search_begin(Dev E)
     ws_load(s, E.state + (size_t)g * GREC);
     tree_trim(t, c);
     c.mode = 1;
-    c.sims_done = 0; c.pending = 0; c.path_len = 0; c.error = 0;
+    c.sims_done = 0; c.sims_started = 0; c.pending = 0; c.error = 0;
     c.search_done = game_status(s, E.rules) != ST_NOT_ENDED ? 1u : 0u;
     ctl_store(c, &E.ctl[g]);
 }
@@ -264,37 +288,51 @@ __device__ __forceinline__ void flush_counters(const Dev& E, const Ctl& c, const
     }
 }
 
-// AlphaZeroMCTS::search leaf branch, after the future resolved (alphazero_mcts.cpp:350-356): expand + backup
+// AlphaZeroMCTS::search leaf branch, after the future resolved (alphazero_mcts.cpp:350-356): expand + backup, for every
+// search thread with a pending leaf, in thread order.  A state another thread has added meanwhile is dropped
+// (StateSimulationsStorage::add, alphazero_mcts.cpp:203-215) and its value still backed up.
 __device__ __forceinline__ void consume_pending(const Dev& E, int g, const Tree& t, Ctl& c, StepCount& k)
 {
     if (!c.pending) return;
     const uint32_t l = lane_id();
-    float pi = E.net_pi[(size_t)g * PI_STRIDE + (l < MOVES ? l : 0)];
-    float v = rdlf(E.net_v[g], 0);
-    uint64_t valid = rfl64(E.leaf_valid[g]);
-    uint32_t kd = reinterpret_cast<const uint32_t*>(E.leaf_key + (size_t)g * GREC)[l & 15u];
-    uint32_t h = rfl(E.leaf_hash[g]);
-    float prior = normalize_prior(pi, valid);
-    if (tree_expand(t, c, kd, h, valid, prior) == NO_NODE) k.drop++;
-    k.evals++;
-    if (c.path_len > 0) {  // path_len == 0: this was setRootState's root expansion (not a simulation)
-        tree_backup(t, c.path_len, v);
-        c.sims_done++;
-        k.sims++;
+    for (int th = 0; th < E.T; th++) {
+        if (!((c.pending >> th) & 1u)) continue;
+        const size_t slot = (size_t)g * E.T + th;
+        float pi = E.net_pi[slot * PI_STRIDE + (l < MOVES ? l : 0)];
+        float v = rdlf(E.net_v[slot], 0);
+        uint64_t valid = rfl64(E.leaf_valid[slot]);
+        uint32_t kd = reinterpret_cast<const uint32_t*>(E.leaf_key + slot * GREC)[l & 15u];
+        uint32_t h = rfl(E.leaf_hash[slot]);
+        if (E.T > 1 && tree_lookup(t, kd, h) != NO_NODE) c.dup_dropped++;
+        else {
+            float prior = normalize_prior(pi, valid);
+            if (tree_expand(t, c, kd, h, valid, prior) == NO_NODE) k.drop++;
+        }
+        k.evals++;
+        const uint32_t plen = plen_get(c, th);
+        if (plen > 0) {  // plen == 0: this was setRootState's root expansion (not a simulation)
+            tree_backup(thread_tree(t, th), plen, v);
+            c.sims_done++;
+            k.sims++;
+        }
     }
     c.pending = 0;
 }
 
 enum : int { RD_DONE = 0, RD_LEAF = 1, RD_FAIL = 2 };
 
-// AlphaZeroMCTS::search from the root (alphazero_mcts.cpp:322-377), iteratively, repeated until the search has its
-// S simulations (RD_DONE), a leaf needs the net (RD_LEAF: leaf record written, c.pending set) or a rule error (RD_FAIL).
-__device__ __forceinline__ int run_descents(const Dev& E, int g, const Tree& t, Ctl& c, const WS& root, int8_t* scratch,
+// AlphaZeroMCTS::threadSimulateJob + search (alphazero_mcts.cpp:310-377) for search thread `th`, iteratively: claim the
+// next simulation from the counter and descend from the root, repeated until the counter is exhausted (RD_DONE), a leaf
+// needs the net (RD_LEAF: leaf record written to slot g * T + th, pending bit set) or a rule error (RD_FAIL).
+__device__ __forceinline__ int run_descents(const Dev& E, int g, const Tree& t0, int th, Ctl& c, const WS& root, int8_t* scratch,
                                             StepCount& k, uint32_t& err_out)
 {
     const Rules R = E.rules;
     const Search S = E.search;
-    while ((int)c.sims_done < S.simulations) {
+    const Tree t = thread_tree(t0, th);
+    const size_t slot = (size_t)g * E.T + th;
+    while ((int)c.sims_started < S.simulations) {
+        c.sims_started++;  // Counter::hasNext
         WS s = root;
         s.rng = c.rng;
         s.err = 0;
@@ -315,10 +353,10 @@ __device__ __forceinline__ int run_descents(const Dev& E, int g, const Tree& t, 
             uint32_t h = key_hash(kd);
             uint32_t idx = tree_lookup(t, kd, h);
             if (idx == NO_NODE) {  // leaf: hand the position to the NN service
-                encode88(s, E.leaf_in + (size_t)g * LEAF_STRIDE);
+                encode88(s, E.leaf_in + slot * LEAF_STRIDE);
                 const uint32_t l = lane_id();
-                if (l < 16) reinterpret_cast<uint32_t*>(E.leaf_key + (size_t)g * GREC)[l] = kd;
-                if (l == 0) { E.leaf_valid[g] = valid; E.leaf_hash[g] = h; }
+                if (l < 16) reinterpret_cast<uint32_t*>(E.leaf_key + slot * GREC)[l] = kd;
+                if (l == 0) { E.leaf_valid[slot] = valid; E.leaf_hash[slot] = h; }
                 leaf = true;
                 break;
             }
@@ -335,12 +373,28 @@ __device__ __forceinline__ int run_descents(const Dev& E, int g, const Tree& t, 
         c.rng = s.rng;
         if (fail) { err_out = s.err; return RD_FAIL; }
         if (leaf) {
-            c.pending = 1;
-            c.path_len = plen;
+            if (plen == 0) c.sims_started--;  // setRootState's root expansion is not one of the S simulations
+            c.pending |= 1u << th;
+            plen_set(c, th, plen);
             return RD_LEAF;
         }
     }
     return RD_DONE;
+}
+
+// One round of AlphaZeroMCTS::simulate for all T search threads of the game, in thread order: every thread without a
+// pending leaf runs descents until it blocks on the net.  RD_LEAF = at least one leaf is waiting; RD_DONE = the counter
+// is exhausted and every claimed simulation is backed up.
+__device__ __forceinline__ int search_round(const Dev& E, int g, const Tree& t, Ctl& c, const WS& root, int8_t* scratch,
+                                            StepCount& k, uint32_t& err_out)
+{
+    for (int th = 0; th < E.T; th++) {
+        if ((c.pending >> th) & 1u) continue;
+        int r = run_descents(E, g, t, th, c, root, scratch, k, err_out);
+        if (r == RD_FAIL) { c.pending = 0; return RD_FAIL; }
+        if (r == RD_LEAF && plen_get(c, th) == 0) break;  // root expansion: the threads start after setRootState
+    }
+    return c.pending ? RD_LEAF : RD_DONE;
 }
 
 // N[lane] and the legal mask of the node of `root` (NO_NODE if the root is not in the tree)
@@ -352,7 +406,7 @@ __device__ __forceinline__ uint32_t root_node(const Tree& t, const WS& root, uin
     if (ridx != NO_NODE) {
         const uint8_t* n = node_ptr(t, ridx);
         const uint32_t l = lane_id();
-        N = reinterpret_cast<const uint32_t*>(n + ND_N)[l < MOVES ? l : 0];
+        N = reinterpret_cast<const uint32_t*>(n + ND_N)[l < MOVES ? l : 0] & N_MASK;
         valid = (uint64_t)rfl(*reinterpret_cast<const uint32_t*>(n + ND_VALID_LO)) |
                 ((uint64_t)rfl(*reinterpret_cast<const uint32_t*>(n + ND_VALID_HI)) << 32);
     }
@@ -368,7 +422,7 @@ __device__ __forceinline__ void selfplay_next_game(const Dev& E, int g, const Tr
     root.rng = rng_seed(c.seed);
     new_game(root);
     c.rng = root.rng;
-    c.nsamples = 0; c.decisions = 0; c.sims_done = 0;
+    c.nsamples = 0; c.decisions = 0; c.sims_done = 0; c.sims_started = 0; c.pending = 0;
     tree_clear(t, c);
 }
 
@@ -428,10 +482,10 @@ __global__ __launch_bounds__(64) void k_tree_step(Dev E)
             }
             root_dirty = true;
             tree_trim(t, c);
-            c.sims_done = 0;
+            c.sims_done = 0; c.sims_started = 0;
         }
         uint32_t err = 0;
-        int r = run_descents(E, g, t, c, root, scratch, k, err);
+        int r = search_round(E, g, t, c, root, scratch, k, err);
         if (r == RD_LEAF) break;
         if (r == RD_FAIL) {
             k.err++;
@@ -501,7 +555,7 @@ __global__ __launch_bounds__(64) void k_arena_step(Dev E)
                 ws_store(root, E.prev_start + (size_t)g * GREC);
             }
             tree_clear(t, c);  // AlphaZeroPlayer::newGame
-            c.sims_done = 0; c.search_active = 0; c.turn_started = 0; c.pending = 0; c.path_len = 0;
+            c.sims_done = 0; c.sims_started = 0; c.search_active = 0; c.turn_started = 0; c.pending = 0;
             c.arena_state = 1;
         }
         // ---- Game::playTurn (game.cpp:112-133)
@@ -538,10 +592,10 @@ __global__ __launch_bounds__(64) void k_arena_step(Dev E)
             fail = root.err != 0 || (root.cur == p && game_status(root, R) == ST_NOT_ENDED);
         } else {
             if (!c.turn_started) { tree_trim(t, c); c.turn_started = 1; }   // the player's own trimNodes
-            if (!c.search_active) { tree_trim(t, c); c.sims_done = 0; c.search_active = 1; }  // simulate -> setRootState
+            if (!c.search_active) { tree_trim(t, c); c.sims_done = 0; c.sims_started = 0; c.search_active = 1; }  // simulate -> setRootState
             c.rng = root.rng;
             uint32_t err = 0;
-            int r = run_descents(E, g, t, c, root, scratch, k, err);
+            int r = search_round(E, g, t, c, root, scratch, k, err);
             root.rng = c.rng;
             if (r == RD_LEAF) break;
             if (r == RD_FAIL) { fail = true; root.err = err; }
@@ -582,7 +636,7 @@ __global__ __launch_bounds__(64) void k_arena_start(Dev E)
     Tree t = tree_of(E, g);
     c.hiwater = (uint32_t)E.C;
     tree_clear(t, c);
-    c.mode = 3; c.sims_done = 0; c.pending = 0; c.path_len = 0; c.search_done = 0; c.error = 0;
+    c.mode = 3; c.sims_done = 0; c.sims_started = 0; c.pending = 0; c.search_done = 0; c.error = 0;
     c.arena_state = 0; c.player_start = 0; c.pair_phase = 0; c.turn_started = 0; c.search_active = 0; c.slot_games = 0;
     c.seed = E.base_seed + (uint32_t)g;
     c.rng = rng_seed(c.seed);
@@ -606,7 +660,7 @@ __global__ __launch_bounds__(64) void k_root_stats(Dev E, uint32_t* n_out, float
     uint32_t N = 0; float Q = 0, P = 0, pi = 0;
     if (idx != NO_NODE) {
         const uint8_t* n = node_ptr(t, idx);
-        N = reinterpret_cast<const uint32_t*>(n + ND_N)[l < MOVES ? l : 0];
+        N = reinterpret_cast<const uint32_t*>(n + ND_N)[l < MOVES ? l : 0] & N_MASK;
         Q = reinterpret_cast<const float*>(n + ND_Q)[l < MOVES ? l : 0];
         P = reinterpret_cast<const float*>(n + ND_P)[l < MOVES ? l : 0];
         uint64_t valid = (uint64_t)rfl(*reinterpret_cast<const uint32_t*>(n + ND_VALID_LO)) |
@@ -636,7 +690,7 @@ __global__ __launch_bounds__(64) void k_pick(Dev E, int sample, uint8_t* moves)
     if (idx != NO_NODE) {
         const uint8_t* n = node_ptr(t, idx);
         const uint32_t l = lane_id();
-        uint32_t N = reinterpret_cast<const uint32_t*>(n + ND_N)[l < MOVES ? l : 0];
+        uint32_t N = reinterpret_cast<const uint32_t*>(n + ND_N)[l < MOVES ? l : 0] & N_MASK;
         uint64_t valid = (uint64_t)rfl(*reinterpret_cast<const uint32_t*>(n + ND_VALID_LO)) |
                          ((uint64_t)rfl(*reinterpret_cast<const uint32_t*>(n + ND_VALID_HI)) << 32);
         float pi = root_policy(N, valid);
@@ -657,7 +711,7 @@ __global__ __launch_bounds__(64) void k_selfplay_start(Dev E)
     c.hiwater = (uint32_t)E.C;
     tree_clear(t, c);
     tree_trim(t, c);
-    c.mode = 2; c.sims_done = 0; c.pending = 0; c.path_len = 0; c.search_done = 0; c.error = 0;
+    c.mode = 2; c.sims_done = 0; c.sims_started = 0; c.pending = 0; c.search_done = 0; c.error = 0;
     c.game_no = 0; c.nsamples = 0; c.decisions = 0; c.status = ST_NOT_ENDED;
     c.seed = E.base_seed + (uint32_t)g;
     WS s;
@@ -682,6 +736,7 @@ extern "C" void azr_default_settings(azr_settings* s)
     s->blocks = 20;
     s->net_dtype = AZR_NET_BF16;
     s->mcts_simulations = 32;
+    s->mcts_threads = 2;
     s->allow_yield = 1;
     s->limit_reinforcement = 1;
     s->limit_attack = 0;
@@ -701,6 +756,7 @@ static hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, n * siz
 extern "C" int azr_engine_create(const azr_settings* s, azr_engine** out)
 {
     if (!s || !out || s->games <= 0 || s->blocks <= 0 || s->mcts_simulations < 0) return AZR_E_INVALID_ARGUMENT;
+    if (s->mcts_threads < 1 || s->mcts_threads > MAX_THREADS) return AZR_E_INVALID_ARGUMENT;
     azr_engine* h = new (std::nothrow) azr_engine();
     if (!h) return AZR_E_HIP;
     h->cfg = *s;
@@ -714,6 +770,7 @@ extern "C" int azr_engine_create(const azr_settings* s, azr_engine** out)
     Dev& d = h->d;
     memset(&d, 0, sizeof d);
     d.G = s->games;
+    d.T = s->mcts_threads;
     int C = s->node_capacity > 0 ? s->node_capacity : 16 * (s->mcts_simulations + 1);
     if (C < 64) C = 64;
     if (C > 65534) C = 65534;
@@ -722,12 +779,13 @@ extern "C" int azr_engine_create(const azr_settings* s, azr_engine** out)
     d.DMAX = std::min(C, 1024);
     d.SCAP = s->sample_capacity > 0 ? s->sample_capacity : 4096;
     d.rules = Rules{s->allow_yield, s->limit_reinforcement, s->limit_attack, s->max_game_rounds, s->min_unit_move};
-    d.search.simulations = s->mcts_simulations;
+    // count = MCTS_SIMULATIONS - MCTS_SIMULATIONS % THREADS_PER_MCTS (alphazero_mcts.cpp:265)
+    d.search.simulations = s->mcts_simulations - s->mcts_simulations % s->mcts_threads;
     d.search.c1 = 1 - s->dir_noise_epsi;
     d.search.c2 = s->dir_noise_epsi * s->dir_noise_value;
     d.search.hp = s->hp_exploration;
     d.search.temperature_threshold = s->temperature_threshold;
-    const size_t G = d.G;
+    const size_t G = d.G, GT = G * d.T;
     HIPCHK(h, dmalloc(&d.state, G * GREC));
     HIPCHK(h, dmalloc(&d.ctl, G));
     HIPCHK(h, dmalloc(&d.nodes, G * C * NODE_BYTES));
@@ -735,13 +793,13 @@ extern "C" int azr_engine_create(const azr_settings* s, azr_engine** out)
     HIPCHK(h, dmalloc(&d.nhash, G * C));
     HIPCHK(h, dmalloc(&d.table, G * d.H));
     HIPCHK(h, dmalloc(&d.freel, G * C));
-    HIPCHK(h, dmalloc(&d.path, G * d.DMAX));
-    HIPCHK(h, dmalloc(&d.leaf_in, G * LEAF_STRIDE));
-    HIPCHK(h, dmalloc(&d.leaf_key, G * GREC));
-    HIPCHK(h, dmalloc(&d.leaf_valid, G));
-    HIPCHK(h, dmalloc(&d.leaf_hash, G));
-    HIPCHK(h, dmalloc(&d.net_pi, G * PI_STRIDE));
-    HIPCHK(h, dmalloc(&d.net_v, G));
+    HIPCHK(h, dmalloc(&d.path, GT * d.DMAX));
+    HIPCHK(h, dmalloc(&d.leaf_in, GT * LEAF_STRIDE));
+    HIPCHK(h, dmalloc(&d.leaf_key, GT * GREC));
+    HIPCHK(h, dmalloc(&d.leaf_valid, GT));
+    HIPCHK(h, dmalloc(&d.leaf_hash, GT));
+    HIPCHK(h, dmalloc(&d.net_pi, GT * PI_STRIDE));
+    HIPCHK(h, dmalloc(&d.net_v, GT));
     HIPCHK(h, dmalloc(&d.stage, G * d.SCAP * STAGE_BYTES));
     d.ring_cap = (unsigned long long)G * d.SCAP;
     HIPCHK(h, dmalloc(&d.ring, (size_t)d.ring_cap * AZR_RECORD_BYTES));
@@ -759,9 +817,9 @@ extern "C" int azr_engine_create(const azr_settings* s, azr_engine** out)
     HIPCHK(h, hipMemsetAsync(d.ctl, 0, G * sizeof(Ctl), h->stream));
     HIPCHK(h, hipMemsetAsync(d.touch, 0, G * C * sizeof(uint32_t), h->stream));
     HIPCHK(h, hipMemsetAsync(d.table, 0, G * d.H * sizeof(uint32_t), h->stream));
-    HIPCHK(h, hipMemsetAsync(d.leaf_in, 0, G * LEAF_STRIDE, h->stream));
-    HIPCHK(h, hipMemsetAsync(d.net_pi, 0, G * PI_STRIDE * sizeof(float), h->stream));
-    HIPCHK(h, hipMemsetAsync(d.net_v, 0, G * sizeof(float), h->stream));
+    HIPCHK(h, hipMemsetAsync(d.leaf_in, 0, GT * LEAF_STRIDE, h->stream));
+    HIPCHK(h, hipMemsetAsync(d.net_pi, 0, GT * PI_STRIDE * sizeof(float), h->stream));
+    HIPCHK(h, hipMemsetAsync(d.net_v, 0, GT * sizeof(float), h->stream));
     HIPCHK(h, hipMemsetAsync(d.ring_count, 0, sizeof(unsigned long long), h->stream));
     HIPCHK(h, hipMemsetAsync(d.counters, 0, sizeof(Counters), h->stream));
     HIPCHK(h, hipMemsetAsync(d.active, 0, sizeof(uint32_t), h->stream));
@@ -965,13 +1023,14 @@ extern "C" int azr_mcts_leaves(azr_engine* h, void* in88, uint8_t* need, int* ac
     uint32_t active = 0;
     int rc = tree_step_host(h, &active);
     if (rc) return rc;
-    const int G = h->d.G;
-    if (in88) HIPCHK(h, hipMemcpy2DAsync(in88, 88, h->d.leaf_in, LEAF_STRIDE, 88, G, hipMemcpyDeviceToHost, h->stream));
+    const int G = h->d.G, T = h->d.T;
+    if (in88) HIPCHK(h, hipMemcpy2DAsync(in88, 88, h->d.leaf_in, LEAF_STRIDE, 88, (size_t)G * T, hipMemcpyDeviceToHost, h->stream));
     if (need) {
         std::vector<uint32_t> p(G);
         HIPCHK(h, hipMemcpy2DAsync(p.data(), 4, &h->d.ctl[0].pending, sizeof(Ctl), 4, G, hipMemcpyDeviceToHost, h->stream));
         SYNC(h);
-        for (int g = 0; g < G; g++) need[g] = (uint8_t)p[g];
+        for (int g = 0; g < G; g++)
+            for (int k = 0; k < T; k++) need[g * T + k] = (uint8_t)((p[g] >> k) & 1u);
     }
     SYNC(h);
     if (active_out) *active_out = (int)active;
@@ -982,9 +1041,9 @@ extern "C" int azr_mcts_apply(azr_engine* h, const float* pi, const float* v)
 {
     ENTER(h);
     if (!pi || !v) return AZR_E_INVALID_ARGUMENT;
-    const int G = h->d.G;
-    HIPCHK(h, hipMemcpy2DAsync(h->d.net_pi, PI_STRIDE * 4, pi, MOVES * 4, MOVES * 4, G, hipMemcpyHostToDevice, h->stream));
-    H2D(h, h->d.net_v, v, (size_t)G * 4);
+    const size_t GT = (size_t)h->d.G * h->d.T;
+    HIPCHK(h, hipMemcpy2DAsync(h->d.net_pi, PI_STRIDE * 4, pi, MOVES * 4, MOVES * 4, GT, hipMemcpyHostToDevice, h->stream));
+    H2D(h, h->d.net_v, v, GT * 4);
     SYNC(h);
     return AZR_OK;
 }
@@ -1000,7 +1059,7 @@ extern "C" int azr_mcts_simulate(azr_engine* h)
         rc = tree_step_host(h, &active);
         if (rc) return rc;
         if (active == 0) break;
-        rc = net_forward(h, h->d.leaf_in, LEAF_STRIDE, h->d.G, h->d.net_pi, h->d.net_v);
+        rc = net_forward(h, h->d.leaf_in, LEAF_STRIDE, h->d.G * h->d.T, h->d.net_pi, h->d.net_v);
         if (rc) return rc;
     }
     // surface per-game errors
@@ -1085,7 +1144,7 @@ extern "C" int azr_selfplay_run(azr_engine* h, int passes)
         if (prof) HIPCHK(h, hipEventRecord(h->ev[3 * k + 1], h->stream));
         h->pe_tower0 = prof ? h->ev[3 * PROF_MAX + 2 * k] : nullptr;
         h->pe_tower1 = prof ? h->ev[3 * PROF_MAX + 2 * k + 1] : nullptr;
-        int rc = net_forward(h, h->d.leaf_in, LEAF_STRIDE, h->d.G, h->d.net_pi, h->d.net_v);
+        int rc = net_forward(h, h->d.leaf_in, LEAF_STRIDE, h->d.G * h->d.T, h->d.net_pi, h->d.net_v);
         h->pe_tower0 = h->pe_tower1 = nullptr;
         if (rc) return rc;
         if (prof) { HIPCHK(h, hipEventRecord(h->ev[3 * k + 2], h->stream)); k++; }
@@ -1199,7 +1258,7 @@ extern "C" int azr_arena_run(azr_engine* h, int passes, int* finished_out)
     for (int p = 0; p < passes; p++) {
         LAUNCH(h, k_arena_step, h->d);
         if (needs_net) {
-            int rc = net_forward(h, h->d.leaf_in, LEAF_STRIDE, h->d.G, h->d.net_pi, h->d.net_v);
+            int rc = net_forward(h, h->d.leaf_in, LEAF_STRIDE, h->d.G * h->d.T, h->d.net_pi, h->d.net_v);
             if (rc) return rc;
         }
     }

@@ -20,6 +20,7 @@ constexpr int NPOS = 42;
 // device view handed to kernels by value
 struct Dev {
     int G, C, H, DMAX, SCAP;
+    int T;                 // THREADS_PER_MCTS: search threads (= leaf slots) per game; slot = g * T + k
     Rules rules;
     Search search;
     uint8_t* state;        // [G][64] game records
@@ -29,13 +30,13 @@ struct Dev {
     uint32_t* nhash;       // [G][C]
     uint32_t* table;       // [G][H]
     uint16_t* freel;       // [G][C]
-    uint32_t* path;        // [G][DMAX]
-    uint8_t* leaf_in;      // [G][LEAF_STRIDE]
-    uint8_t* leaf_key;     // [G][64]
-    uint64_t* leaf_valid;  // [G]
-    uint32_t* leaf_hash;   // [G]
-    float* net_pi;         // [G][PI_STRIDE]
-    float* net_v;          // [G]
+    uint32_t* path;        // [G][T][DMAX]
+    uint8_t* leaf_in;      // [G*T][LEAF_STRIDE]
+    uint8_t* leaf_key;     // [G*T][64]
+    uint64_t* leaf_valid;  // [G*T]
+    uint32_t* leaf_hash;   // [G*T]
+    float* net_pi;         // [G*T][PI_STRIDE]
+    float* net_v;          // [G*T]
     uint8_t* stage;        // [G][SCAP][STAGE_BYTES]
     uint8_t* ring;         // [RCAP][265]
     unsigned long long* ring_count;

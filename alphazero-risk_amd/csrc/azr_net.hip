@@ -281,8 +281,8 @@ int azr::net_alloc(azr_engine* h)
     HIPCHK(h, hipMalloc((void**)&x->d_flat, count * sizeof(float)));
     HIPCHK(h, hipMalloc((void**)&x->d_fold, (14 + (size_t)2 * n.blocks * 2 * NF) * sizeof(float)));
     if (h->cfg.net_dtype == AZR_NET_F32) {
-        HIPCHK(h, hipMalloc((void**)&n.actX, (size_t)h->d.G * NPOS * NF * sizeof(float)));
-        HIPCHK(h, hipMalloc((void**)&n.actT, (size_t)h->d.G * NPOS * NF * sizeof(float)));
+        HIPCHK(h, hipMalloc((void**)&n.actX, (size_t)h->d.G * h->d.T * NPOS * NF * sizeof(float)));
+        HIPCHK(h, hipMalloc((void**)&n.actT, (size_t)h->d.G * h->d.T * NPOS * NF * sizeof(float)));
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_f32), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       FRAME * NF * (int)sizeof(float)));
     } else {
@@ -374,7 +374,7 @@ static int net_f32_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, 
 int azr::net_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v)
 {
     if (n <= 0) return AZR_OK;
-    if (n > h->d.G) { h->err = "net_forward: batch larger than the engine's game count"; return AZR_E_INVALID_ARGUMENT; }
+    if (n > h->d.G * h->d.T) { h->err = "net_forward: batch larger than the engine's leaf slots"; return AZR_E_INVALID_ARGUMENT; }
     if (h->cfg.net_dtype == AZR_NET_F32) return net_f32_forward(h, d_in88, in_stride, n, d_pi, d_v);
     return net_bf16_forward(h, d_in88, in_stride, n, d_pi, d_v);
 }

@@ -7,7 +7,12 @@
 //     StateSimulationsStorage::exist / State::equalFields, alphazero_mcts.cpp:189-201, state/state.cpp:111-135),
 //   * per-node "touch" stamps instead of the visited flag: trimNodes (alphazero_mcts.cpp:229-245) keeps exactly
 //     the nodes created or selected-through since the previous trim,
-//   * a path stack so backup (alphazero_mcts.cpp:367-375) is one lane-parallel pass after the leaf's value arrives.
+//   * a path stack per search thread so backup (alphazero_mcts.cpp:367-375) is one lane-parallel pass after the leaf's
+//     value arrives,
+//   * THREADS_PER_MCTS (src/settings.h:44, alphazero_mcts.cpp:255-320) as T lock-stepped descents per game: the
+//     reference's T threads block together in predictFuture until the batch is evaluated; here thread k = leaf slot
+//     g * T + k of the net batch, threads run in index order, and SimulationValue::active_N (the virtual-loss count of
+//     getNextBestMoveAndSetVisited) lives in the top byte of the N word.
 // Everything is private to the game's wave: no atomics, no inter-wave sharing.
 #pragma once
 #include "azr_wave.hpp"
@@ -17,6 +22,9 @@ namespace azr {
 constexpr int NODE_BYTES = 640;
 constexpr int ND_KEY = 0, ND_SUMN = 64, ND_VALID_LO = 68, ND_VALID_HI = 72, ND_P = 80, ND_Q = 256, ND_N = 432;
 constexpr uint32_t NO_NODE = 0xffffffffu;
+constexpr int MAX_THREADS = 8;             // THREADS_PER_MCTS upper bound of this build
+constexpr uint32_t N_MASK = 0x00ffffffu;   // N word: visit count in the low 24 bits, active_N in the top 8
+constexpr uint32_t ACT_ONE = 0x01000000u;
 
 struct Search {  // reference Settings the search reads (src/settings.h:45,61-64)
     int simulations;
@@ -31,8 +39,8 @@ struct alignas(128) Ctl {
     uint32_t mode;         // 0 idle | 1 host-stepped search | 2 device self-play
     uint32_t search_id;    // stamp of the current search (trim count)
     uint32_t sims_done;
-    uint32_t pending;      // leaf written, waiting for the net's (pi, v)
-    uint32_t path_len;
+    uint32_t pending;      // bit k: search thread k has a leaf written, waiting for the net's (pi, v)
+    uint32_t sims_started; // Counter::i of AlphaZeroMCTS::simulate: descents claimed (sims_done = descents backed up)
     uint32_t nfree;
     uint32_t hiwater;
     uint32_t search_done;
@@ -51,7 +59,9 @@ struct alignas(128) Ctl {
     uint32_t turn_started; // AlphaZeroPlayer::takeTurn in progress (its own trimNodes done)
     uint32_t search_active;// AlphaZeroMCTS::simulate in progress
     uint32_t slot_games;   // games finished in this slot
-    uint32_t pad[10];
+    uint32_t dup_dropped;  // StateSimulationsStorage::duplicatedStatesDropped
+    uint32_t plen[MAX_THREADS];  // path length of thread k's pending descent (0 = setRootState's root expansion)
+    uint32_t pad[1];
 };
 static_assert(sizeof(Ctl) == 128, "Ctl must be one line");
 
@@ -61,7 +71,7 @@ struct Tree {  // this game's slices of the engine's HBM arrays
     uint32_t* nhash;     // [C]   32-bit key hash
     uint32_t* table;     // [H]   0 = empty, else tag16 << 16 | (node + 1)
     uint16_t* freel;     // [C]   free-slot stack
-    uint32_t* path;      // [DMAX] node | move << 16 | flip << 24
+    uint32_t* path;      // [DMAX] node | move << 16 | flip << 24   (the current search thread's stack)
     int C, H, DMAX;
 };
 
@@ -249,8 +259,10 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
-// StateSimulations::getNextBestMoveAndSetVisited (alphazero_mcts.cpp:67-119) at one search thread (active_N is
-// always 0 when a node is selected, so the "skip" rule never fires).  Float ops in the reference's order, no FMA.
+// StateSimulations::getNextBestMoveAndSetVisited (alphazero_mcts.cpp:67-119).  Float ops in the reference's order, no
+// FMA.  The reference's loop keeps the first strict maximum in unordered_map iteration order over the moves that are
+// not "skipped" (N == 0 && active_N == 1: another thread is already exploring that unobserved move); only when every
+// candidate is skipped does it fall back to the best skipped one.  active_N++ on the chosen move.
 __device__ __forceinline__ uint32_t tree_select(const Tree& t, uint32_t idx, const Search& S, uint32_t stamp, int8_t* scratch)
 {
     const uint8_t* n = node_ptr(t, idx);
@@ -261,19 +273,26 @@ __device__ __forceinline__ uint32_t tree_select(const Tree& t, uint32_t idx, con
                            ((uint64_t)rfl(*reinterpret_cast<const uint32_t*>(n + ND_VALID_HI)) << 32);
     const float P = reinterpret_cast<const float*>(n + ND_P)[ll];
     const float Q = reinterpret_cast<const float*>(n + ND_Q)[ll];
-    const uint32_t N = reinterpret_cast<const uint32_t*>(n + ND_N)[ll];
+    const uint32_t W = reinterpret_cast<const uint32_t*>(n + ND_N)[ll];
+    const uint32_t N = W & N_MASK, act = W >> 24;
     if (l == 0) t.touch[idx] = stamp;  // visited = true
     const float noiseP = __fadd_rn(__fmul_rn(S.c1, P), S.c2);
     const float v = __fmul_rn(__fmul_rn(noiseP, S.hp), __fsqrt_rn(__fadd_rn(1.0f, (float)sumN)));
     const float nn = __fadd_rn(1.0f, (float)N);
     float u = __fadd_rn(Q, __fdiv_rn(v, nn));
     const bool ok = l < MOVES && ((valid >> l) & 1ULL);
-    if (!ok) u = -INFINITY;
-    const float best = wave_max(u);
-    const uint64_t ties = ballot64(ok && u == best && u > -INFINITY);
-    if (ties == 0) return NONE;  // all NaN / -inf: the reference's moveValues.at(None) throws
-    if ((ties & (ties - 1)) == 0) return (uint32_t)ctz64(ties);
-    return umap_first(valid, ties, scratch);
+    const bool skip = ok && N == 0 && act == 1;
+    float best = wave_max((ok && !skip) ? u : -INFINITY);
+    uint64_t ties = ballot64(ok && !skip && u == best && u > -INFINITY);
+    if (ties == 0) {  // bestMove == None: duplicate the best skipped request (alphazero_mcts.cpp:111-114)
+        best = wave_max(skip ? u : -INFINITY);
+        ties = ballot64(skip && u == best && u > -INFINITY);
+        if (ties == 0) return NONE;  // all NaN / -inf: the reference's moveValues.at(None) throws
+    }
+    const uint32_t mv = (ties & (ties - 1)) == 0 ? (uint32_t)ctz64(ties) : umap_first(valid, ties, scratch);
+    if (l == mv) reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(n) + ND_N)[l] = W + ACT_ONE;  // sv.active_N++
+    wave_mem_sync();
+    return mv;
 }
 
 // NNOutputData::normalize (alphazero_nn_data.cpp:3-27): sequential fp32 sum over the legal entries, index order
@@ -332,11 +351,11 @@ __device__ __forceinline__ void tree_backup(const Tree& t, uint32_t path_len, fl
             uint32_t mv = (e >> 16) & 0xffu;
             float* q = reinterpret_cast<float*>(n + ND_Q) + mv;
             uint32_t* nn = reinterpret_cast<uint32_t*>(n + ND_N) + mv;
-            uint32_t N = *nn;
+            const uint32_t W = *nn, N = W & N_MASK;
             float Q = *q;
             Q = N == 0 ? v : __fdiv_rn(__fadd_rn(__fmul_rn((float)N, Q), v), (float)(N + 1u));
             *q = Q;
-            *nn = N + 1u;
+            *nn = W + 1u - ((W >> 24) ? ACT_ONE : 0u);  // N++, active_N--
             *reinterpret_cast<uint32_t*>(n + ND_SUMN) += 1u;
         }
         carry = (carry + (uint32_t)popc64(fm)) & 1u;

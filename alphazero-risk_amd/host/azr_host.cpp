@@ -158,6 +158,7 @@ void Settings::toEngine(azr_settings& s, int device) const
     s.blocks = BLOCKS;
     s.net_dtype = NET_DTYPE == "f32" ? AZR_NET_F32 : AZR_NET_BF16;
     s.mcts_simulations = MCTS_SIMULATIONS;
+    s.mcts_threads = std::max(1, std::min(8, THREADS_PER_MCTS));
     s.allow_yield = ALLOW_YIELD;
     s.limit_reinforcement = LIMIT_REINFORCEMENT_MOVES;
     s.limit_attack = LIMIT_ATTACK_MOVES;

@@ -34,9 +34,10 @@ def flop_per_sim(blocks):
     return 2 * mac
 
 
-def cpu_baseline(blocks, sims, seconds_budget=25.0):
-    """the oracle (CPU port of the reference path, t = 1, one game per thread, fp32 CPU net) on this box's host
-    cores, bounded sample: one decision (sims simulations + root expansion) per thread"""
+def cpu_baseline(blocks, sims, mcts_threads, seconds_budget=25.0):
+    """the oracle (CPU port of the reference path, one game per OS thread, the game's THREADS_PER_MCTS search threads in
+    the same lock-step schedule as the device, fp32 CPU net) on this box's host cores, bounded sample: one decision
+    (sims simulations + root expansion) per game"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import azr_testlib as T
 
@@ -45,7 +46,7 @@ def cpu_baseline(blocks, sims, seconds_budget=25.0):
     threads = max(1, min(cores, 16))  # a 1-GPU box has a 16-core CPU share; "cores" reported = threads actually used
     flat = T.make_net_flat(blocks)
     net = T.OrcNet(blocks, flat.ctypes.data_as(T.f32p))
-    cfg = T.default_settings(mcts_simulations=sims)
+    cfg = T.default_settings(mcts_simulations=sims, mcts_threads=mcts_threads)
     orc.orc_bench_selfplay.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p]
     s, e, sec = C.c_uint64(), C.c_uint64(), C.c_double()
@@ -58,7 +59,7 @@ def cpu_baseline(blocks, sims, seconds_budget=25.0):
     orc.orc_bench_selfplay(C.byref(cfg), C.byref(net), 20260001, threads, decisions, C.byref(s), C.byref(e),
                            C.byref(sec))
     return {"value": s.value / sec.value, "unit": "MCTS simulations/s", "cores": threads, "kind": "port",
-            "sample": f"{threads} games (one per thread, t=1), {decisions} decision(s) x {sims} sims each, "
+            "sample": f"{threads} games (one per host thread, THREADS_PER_MCTS={mcts_threads}), {decisions} decision(s) x {sims} sims each, "
                       f"{blocks}-block fp32 CPU net, {sec.value:.1f} s"}
 
 
@@ -69,6 +70,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--games", type=int, default=256, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=100)
+    ap.add_argument("--threads", type=int, default=2,
+                    help="THREADS_PER_MCTS (-t): search threads per game; 2 is the reference's default (src/settings.h:44)")
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -103,7 +106,7 @@ def main():
     from importlib import import_module
     shard = import_module("alphazero-risk_amd.shard")
     eng = pkg.Engine(a.games, blocks=a.blocks, sims=a.sims, dtype=pkg.NET_BF16 if a.dtype == "bf16" else pkg.NET_F32,
-                     device=local)
+                     device=local, threads=a.threads)
     eng.init_random(20260002)
     eng.selfplay_start(shard.rank_base_seed(20260001, rank))
 
@@ -159,33 +162,37 @@ def main():
     if rank == 0:
         fps = flop_per_sim(a.blocks)
         net_s = prof["net_ms"] * 1e-3
-        achieved = a.games * fps / net_s if net_s > 0 else 0.0
+        # algorithmic work of one launch = the leaves that were actually waiting for the net (idle slots are not counted)
+        leaves_per_launch = evals / max(1, a.steps * world)
+        achieved = leaves_per_launch * fps / net_s if net_s > 0 else 0.0
         peak = PEAK_BF16 if a.dtype == "bf16" else PEAK_F32
         out = {
             "metric": "MCTS simulations/s", "value": sims / dt, "unit": "simulations/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"{a.games} concurrent self-play games/GPU x {a.sims} MCTS sims/move, "
-                                   f"{a.blocks}-block 256-filter random-init net (BASELINE configs[1])",
-                       "games_per_gpu": a.games, "sims_per_move": a.sims, "blocks": a.blocks,
+                                   f"THREADS_PER_MCTS {a.threads}, {a.blocks}-block 256-filter random-init net (BASELINE configs[1])",
+                       "games_per_gpu": a.games, "sims_per_move": a.sims, "mcts_threads": a.threads, "blocks": a.blocks,
                        "parallelism": f"games sharded x{world}, no data-path collective; 1 all_gather of records"},
             "self_play_games_per_s": games_rate["games_per_s"] if games_rate else games / dt,
             "self_play_games_window": games_rate, "decisions_per_s": decisions / dt,
             "net_evals_per_s": evals / dt, "mean_depth": levels / max(1, sims),
             "games_finished": games, "records_gathered": int(allrecs.shape[0]), "errors": errors,
             "nodes_dropped": dropped,
-            "roofline": {"bound": "mfma", "kernel": "k_tower_bf16 (one whole net forward of G leaves: stem + 2B conv layers + both heads, one launch)"
+            "roofline": {"bound": "mfma", "kernel": "k_tower_bf16 (one whole net forward of the G x T leaf slots: stem + 2B conv layers + both heads, one launch)"
                          if a.dtype == "bf16" else "fp32 conv chain", "achieved": achieved / 1e12,
                          "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "flop_per_launch": a.games * fps, "avg_launch_ms": prof["net_ms"],
+                         "flop_per_launch": leaves_per_launch * fps, "leaves_per_launch": leaves_per_launch,
+                         "leaf_slots_per_launch": a.games * a.threads, "avg_launch_ms": prof["net_ms"],
                          "tree_step_avg_ms": prof["tree_ms"], "timed_launches": prof["launches"],
                          # HBM-side bytes per launch from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction),
-                         # profiles/r01_final_pmc_fetch_write_g256_s100_b20.txt — measured for exactly this configuration
-                         "traffic": (2 * 186413.07 + 56.0) * 1024
-                         if (a.games, a.blocks, a.dtype) == (256, 20, "bf16") else None},
+                         # profiles/r01_final_pmc_fetch_write_g256_s100_t{1,2}_b20.txt — measured for exactly these configurations
+                         "traffic": {(256, 1, 20, "bf16"): (2 * 186413.07 + 56.0) * 1024,
+                                     (256, 2, 20, "bf16"): (2 * 185944.59 + 96.0) * 1024}.get(
+                                         (a.games, a.threads, a.blocks, a.dtype))},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.blocks, a.sims)
+            out["cpu_baseline"] = cpu_baseline(a.blocks, a.sims, a.threads)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -51,6 +51,8 @@ typedef struct azr_settings {
     int32_t blocks;                /* residual blocks B (CMakeLists.txt:15 BLOCKS, 20) */
     int32_t net_dtype;             /* AZR_NET_F32 | AZR_NET_BF16 */
     int32_t mcts_simulations;      /* MCTS_SIMULATIONS (--mcts) */
+    int32_t mcts_threads;          /* THREADS_PER_MCTS (-t, settings.h:44; default 2): T lock-stepped search threads per
+                                      game with the reference's active_N virtual loss; 1..8.  Leaf slots = games * T. */
     int32_t allow_yield;           /* ALLOW_YIELD (--allow-yield) */
     int32_t limit_reinforcement;   /* LIMIT_REINFORCEMENT_MOVES (--limit-reinforcement) */
     int32_t limit_attack;          /* LIMIT_ATTACK_MOVES (--limit-attack) */
@@ -119,12 +121,15 @@ int azr_nn_train_reset(azr_engine* h);
 /* ---- search: AlphaZeroMCTS / StateSimulationsStorage (alphazero_mcts.h:55-95) ---------------------------- */
 int azr_mcts_clear(azr_engine* h);   /* clearNodes (alphazero_mcts.cpp:223-227), all games */
 int azr_mcts_trim(azr_engine* h);    /* trimNodes  (alphazero_mcts.cpp:229-245), all games */
-/* AlphaZeroMCTS::simulate (alphazero_mcts.cpp:255-307) at THREADS_PER_MCTS = 1 for all G roots in lock-step:
- * trim, expand the root if unknown, then mcts_simulations searches per game.  Finished games idle. */
+/* AlphaZeroMCTS::simulate (alphazero_mcts.cpp:255-307) for all G roots in lock-step: trim, expand the root if unknown,
+ * then mcts_simulations - mcts_simulations % mcts_threads searches per game by mcts_threads search threads that block
+ * together at the NN seam (thread k of game g = leaf slot g * T + k; threads run in index order — one of the
+ * reference's possible schedules, and the only one at T = 1).  Finished games idle. */
 int azr_mcts_simulate(azr_engine* h);
 /* The same search split at the NN seam (predictFuture, alphazero_mcts.cpp:350-351), so a caller can supply
  * priors/values itself: begin -> { leaves -> [evaluate] -> apply }* until *active_out == 0. */
 int azr_mcts_begin(azr_engine* h);
+/* in88_host [G*T][88], need_eval_host [G*T], pi_host [G*T][43], v_host [G*T]; slot = g * T + k */
 int azr_mcts_leaves(azr_engine* h, void* in88_host, uint8_t* need_eval_host, int* active_out);
 int azr_mcts_apply(azr_engine* h, const float* pi_host, const float* v_host);
 /* root statistics of the last search: N[G][43]; Q,P optional */

@@ -25,6 +25,7 @@ void orc_default_settings(orc_settings* s)
     s->dir_noise_value = 0.3f; /* `float DIR_NOISE_VALUE = 0.3;` double literal narrowed to float */
     s->dir_noise_epsi = 0.25f;
     s->temperature_threshold = 15 + 28;
+    s->mcts_threads = 1;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1206,8 +1207,22 @@ void orc_uniform_eval(void* ctx, const uint8_t* in88, float* pi, float* v)
 }
 
 /* ------------------------------------------------------------------------------------------------
- * MCTS (player/alpha_zero/alphazero_mcts.{h,cpp}) at THREADS_PER_MCTS = 1
+ * MCTS (player/alpha_zero/alphazero_mcts.{h,cpp}).  THREADS_PER_MCTS = T search threads are run in
+ * lock-step: the reference's threads all block in predictFuture until the batch is evaluated
+ * (alphazero_mcts.cpp:262-265), so one round = [every thread with an evaluated leaf: store.add +
+ * backup, in thread order] then [every thread: claim simulations and descend until it needs the net, in
+ * thread order].  That is one of the reference's possible schedules and the only one at T = 1.
  * ---------------------------------------------------------------------------------------------- */
+#define ORC_MAX_THREADS 8
+#define ORC_MAX_DEPTH 1024
+typedef struct {
+    int pending, plen;
+    int node[ORC_MAX_DEPTH];
+    uint8_t mv[ORC_MAX_DEPTH], flip[ORC_MAX_DEPTH];
+    orc_state leaf;
+    uint64_t valid;
+} orc_thread;
+
 typedef struct {
     orc_state key;
     float Q[ORC_MOVES], P[ORC_MOVES];
@@ -1225,7 +1240,8 @@ struct orc_mcts {
     orc_settings cfg;
     orc_node* nodes;
     int count, cap;
-    uint64_t sims, evals, levels;
+    uint64_t sims, evals, levels, dup_dropped;
+    orc_thread* th;
 };
 
 orc_mcts* orc_mcts_create(const orc_settings* cfg)
@@ -1234,9 +1250,13 @@ orc_mcts* orc_mcts_create(const orc_settings* cfg)
     m->cfg = *cfg;
     m->cap = 256;
     m->nodes = (orc_node*)malloc(sizeof(orc_node) * (size_t)m->cap);
+    if (m->cfg.mcts_threads < 1) m->cfg.mcts_threads = 1;
+    if (m->cfg.mcts_threads > ORC_MAX_THREADS) m->cfg.mcts_threads = ORC_MAX_THREADS;
+    m->th = (orc_thread*)calloc((size_t)m->cfg.mcts_threads, sizeof(orc_thread));
     return m;
 }
-void orc_mcts_destroy(orc_mcts* m) { if (m) { free(m->nodes); free(m); } }
+void orc_mcts_destroy(orc_mcts* m) { if (m) { free(m->nodes); free(m->th); free(m); } }
+uint64_t orc_mcts_dup_count(const orc_mcts* m) { return m->dup_dropped; }
 void orc_mcts_clear(orc_mcts* m) { m->count = 0; }                     /* clearNodes (:223-227) */
 int orc_mcts_node_count(const orc_mcts* m) { return m->count; }
 uint64_t orc_mcts_sim_count(const orc_mcts* m) { return m->sims; }
@@ -1323,63 +1343,98 @@ static void add_value(orc_node* n, int mv, float v)
     n->sumN++;
 }
 
-/* AlphaZeroMCTS::search (:322-377) */
-static int search(orc_mcts* m, orc_state* s, orc_rng* r, orc_eval_fn eval, void* ctx, float* out)
+/* the unwinding of AlphaZeroMCTS::search's recursion (:367-375): sign flips where the mover changed */
+static void backup(orc_mcts* m, const orc_thread* t, float v)
 {
-    int gs = orc_game_status(s, &m->cfg);
-    if (gs != ORC_NOT_ENDED) {
-        if (gs == ORC_DRAW) { *out = 0.0f; return ORC_OK; }
-        *out = gs == s->cur ? 1.0f : -1.0f;
-        return ORC_OK;
+    for (int i = t->plen - 1; i >= 0; i--) {
+        if (t->flip[i]) v = -v;
+        add_value(&m->nodes[t->node[i]], t->mv[i], v); /* nodes[] may have been realloc'ed: index, not pointer */
     }
-    uint64_t valid = orc_valid_moves(s, &m->cfg);
-    if (valid == 0) return ORC_INVALID_ARGUMENT;
-    int idx = find_node(m, s);
-    if (idx < 0) {
-        uint8_t in88[88];
-        float pi[ORC_MOVES], v;
-        orc_encode(s, in88);
-        eval(ctx, in88, pi, &v);
-        m->evals++;
-        orc_normalize(pi, valid);
-        add_node(m, s, pi, v, valid);
-        *out = v;
-        return ORC_OK;
-    }
-    m->levels++;
-    int best = next_best_move(&m->cfg, &m->nodes[idx]);
-    if (best == ORC_NONE) return ORC_LOGIC_ERROR; /* moveValues.at(None) throws out_of_range */
-    int cur = s->cur;
-    TRY(orc_make_move(s, best, r, &m->cfg));
-    int nxt = s->cur;
-    float nv;
-    TRY(search(m, s, r, eval, ctx, &nv));
-    if (cur != nxt) nv = -nv;
-    add_value(&m->nodes[idx], best, nv); /* nodes[] may have been realloc'ed: index, not pointer */
-    *out = nv;
-    return ORC_OK;
 }
 
-/* AlphaZeroMCTS::simulate + setRootState (:255-307), THREADS_PER_MCTS = 1 */
+/* AlphaZeroMCTS::search (:322-377) from the root down to a terminal state (*leaf = 0, backed up) or to a state that
+ * is not in the store (*leaf = 1: the thread blocks in predictFuture) */
+static int descend(orc_mcts* m, orc_thread* t, const orc_state* root, orc_rng* r, int* leaf)
+{
+    orc_state s = *root;
+    t->plen = 0;
+    for (;;) {
+        int gs = orc_game_status(&s, &m->cfg);
+        if (gs != ORC_NOT_ENDED) {
+            backup(m, t, gs == ORC_DRAW ? 0.0f : (gs == s.cur ? 1.0f : -1.0f));
+            *leaf = 0;
+            return ORC_OK;
+        }
+        uint64_t valid = orc_valid_moves(&s, &m->cfg);
+        if (valid == 0) return ORC_INVALID_ARGUMENT;
+        int idx = find_node(m, &s);
+        if (idx < 0) {
+            t->leaf = s;
+            t->valid = valid;
+            t->pending = 1;
+            *leaf = 1;
+            return ORC_OK;
+        }
+        m->levels++;
+        int best = next_best_move(&m->cfg, &m->nodes[idx]);
+        if (best == ORC_NONE) return ORC_LOGIC_ERROR; /* moveValues.at(None) throws out_of_range */
+        int cur = s.cur;
+        TRY(orc_make_move(&s, best, r, &m->cfg));
+        if (t->plen >= ORC_MAX_DEPTH) return ORC_LOGIC_ERROR;
+        t->node[t->plen] = idx;
+        t->mv[t->plen] = (uint8_t)best;
+        t->flip[t->plen] = (uint8_t)(cur != s.cur);
+        t->plen++;
+    }
+}
+
+/* the leaf branch of search after the future resolved (:350-356) */
+static void expand_leaf(orc_mcts* m, const orc_state* s, uint64_t valid, orc_eval_fn eval, void* ctx, float* v)
+{
+    uint8_t in88[88];
+    float pi[ORC_MOVES];
+    orc_encode(s, in88);
+    eval(ctx, in88, pi, v);
+    m->evals++;
+    orc_normalize(pi, valid);
+    if (find_node(m, s) < 0) add_node(m, s, pi, *v, valid);
+    else m->dup_dropped++; /* StateSimulationsStorage::add (:203-215) */
+}
+
+/* AlphaZeroMCTS::simulate + setRootState + threadSimulateJob (:255-320) */
 int orc_mcts_simulate(orc_mcts* m, const orc_state* root, orc_rng* r, orc_eval_fn eval, void* ctx)
 {
+    const int T = m->cfg.mcts_threads;
     orc_mcts_trim(m);
     if (find_node(m, root) < 0) {
-        uint64_t valid = orc_valid_moves(root, &m->cfg);
-        uint8_t in88[88];
-        float pi[ORC_MOVES], v;
-        orc_encode(root, in88);
-        eval(ctx, in88, pi, &v);
-        m->evals++;
-        orc_normalize(pi, valid);
-        add_node(m, root, pi, v, valid);
-    }
-    int count = m->cfg.mcts_simulations; /* - (sims % threads), threads = 1 */
-    for (int i = 0; i < count; i++) {
-        orc_state copy = *root;
         float v;
-        TRY(search(m, &copy, r, eval, ctx, &v));
-        m->sims++;
+        expand_leaf(m, root, orc_valid_moves(root, &m->cfg), eval, ctx, &v);
+    }
+    const int count = m->cfg.mcts_simulations - m->cfg.mcts_simulations % T;
+    int started = 0;
+    for (int k = 0; k < T; k++) m->th[k].pending = 0;
+    for (;;) {
+        for (int k = 0; k < T; k++) {
+            orc_thread* t = &m->th[k];
+            if (!t->pending) continue;
+            float v;
+            expand_leaf(m, &t->leaf, t->valid, eval, ctx, &v);
+            backup(m, t, v);
+            m->sims++;
+            t->pending = 0;
+        }
+        int waiting = 0;
+        for (int k = 0; k < T; k++) {
+            orc_thread* t = &m->th[k];
+            while (started < count) { /* Counter::hasNext */
+                int leaf = 0;
+                started++;
+                TRY(descend(m, t, root, r, &leaf));
+                if (leaf) { waiting++; break; }
+                m->sims++;
+            }
+        }
+        if (!waiting) break;
     }
     return ORC_OK;
 }

@@ -39,6 +39,8 @@ typedef struct {
     float dir_noise_value;      /* DIR_NOISE_VALUE          0.3 */
     float dir_noise_epsi;       /* DIR_NOISE_EPSI          0.25 */
     int temperature_threshold;  /* TEMPERATURE_TRESHOLD      43 */
+    int mcts_threads;           /* THREADS_PER_MCTS (reference default 2; here 1 = the deterministic schedule).  T > 1
+                                   = T search threads in lock-step, thread order 0..T-1 (see orc_mcts_simulate) */
 } orc_settings;
 
 void orc_default_settings(orc_settings* s);
@@ -137,6 +139,7 @@ int orc_pick_random(const float* pi43, orc_rng* r);
 uint64_t orc_mcts_sim_count(const orc_mcts* m);   /* completed search() descents */
 uint64_t orc_mcts_eval_count(const orc_mcts* m);  /* net evaluations (leaf + root) */
 uint64_t orc_mcts_level_count(const orc_mcts* m); /* inner-node levels visited (for mean depth) */
+uint64_t orc_mcts_dup_count(const orc_mcts* m);   /* duplicatedStatesDropped (T > 1 only) */
 
 /* one self-play game as alphazero_trainer.cpp:80-119; records are the 265-byte on-disk layout.
  * Returns number of records written (<= cap) or -1 on error. */

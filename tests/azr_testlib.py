@@ -25,7 +25,7 @@ class OrcSettings(C.Structure):
     _fields_ = [("allow_yield", C.c_int), ("limit_reinforcement", C.c_int), ("limit_attack", C.c_int),
                 ("max_game_rounds", C.c_int), ("min_unit_move", C.c_int), ("mcts_simulations", C.c_int),
                 ("hp_exploration", C.c_float), ("dir_noise_value", C.c_float), ("dir_noise_epsi", C.c_float),
-                ("temperature_threshold", C.c_int)]
+                ("temperature_threshold", C.c_int), ("mcts_threads", C.c_int)]
 
 
 class OrcPlayer(C.Structure):

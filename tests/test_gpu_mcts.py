@@ -1,5 +1,7 @@
 """GPU parity, search rows a15-a24: flattened-array MCTS against the oracle's restatement of
-alphazero_mcts.cpp at one search thread.  The net is taken out of the comparison by feeding both sides the
+alphazero_mcts.cpp — at one search thread (the reference's only deterministic configuration) and at
+THREADS_PER_MCTS = 2 / 4 in the lock-step schedule both sides implement (virtual loss through active_N, duplicate
+leaf requests dropped, count = S - S % T).  The net is taken out of the comparison by feeding both sides the
 same (pi, v): either a stub evaluated on the host for the device's leaves (azr_mcts_leaves / azr_mcts_apply),
 or the device net itself called back from the oracle.  Bit-exact: visit counts N, Q, priors P, policies,
 picked moves, next states, RNG streams, (s, pi, z) records.
@@ -21,8 +23,8 @@ FM = T.data_field_mask()
 def host_stub_search(eng, orc, stub):
     """azr_mcts_simulate with the NN seam served on the host by an oracle stub net"""
     eng.mcts_begin()
-    pi = np.zeros((eng.G, 43), np.float32)
-    v = np.zeros(eng.G, np.float32)
+    pi = np.zeros((eng.G * eng.T, 43), np.float32)     # leaf slot = game * T + search thread
+    v = np.zeros(eng.G * eng.T, np.float32)
     vv = C.c_float(0)
     for _ in range(100000):
         x, need, active = eng.mcts_leaves()
@@ -35,8 +37,10 @@ def host_stub_search(eng, orc, stub):
     raise AssertionError("search did not terminate")
 
 
-@pytest.mark.parametrize("stub_name,sims", [("orc_hash_eval", 24), ("orc_uniform_eval", 16), ("orc_hash_eval", 100)])
-def test_search_tree_reuse_and_moves_bit_exact(orc, stub_name, sims):
+@pytest.mark.parametrize("stub_name,sims,threads", [("orc_hash_eval", 24, 1), ("orc_uniform_eval", 16, 1), ("orc_hash_eval", 100, 1),
+                                                    ("orc_hash_eval", 25, 2), ("orc_uniform_eval", 16, 2),
+                                                    ("orc_hash_eval", 102, 4), ("orc_uniform_eval", 23, 3)])
+def test_search_tree_reuse_and_moves_bit_exact(orc, stub_name, sims, threads):
     """several consecutive decisions per game (tree reuse through trimNodes), positions from all phases"""
     stub = getattr(orc, stub_name)
     stub.argtypes = [C.c_void_p, T.u8p, T.f32p, C.c_void_p]
@@ -44,8 +48,8 @@ def test_search_tree_reuse_and_moves_bit_exact(orc, stub_name, sims):
     # starting positions: every 29th golden state (setup, reinforcement, attack, mobilisation, fortify, late game)
     states = gold["states"][::29][:96]
     G = len(states)
-    cfg = T.default_settings(mcts_simulations=sims)
-    eng = pkg().Engine(G, blocks=1, sims=sims, dtype=pkg().NET_F32)
+    cfg = T.default_settings(mcts_simulations=sims, mcts_threads=threads)
+    eng = pkg().Engine(G, blocks=1, sims=sims, dtype=pkg().NET_F32, threads=threads)
     eng.set_states(states)
     seeds = np.arange(500, 500 + G, dtype=np.uint32)
     eng.set_rng(seeds)
@@ -113,13 +117,14 @@ def test_player_seam_extra_trim_empties_the_tree(orc):
     eng.close()
 
 
-def test_full_selfplay_games_device_resident_vs_oracle(orc):
+@pytest.mark.parametrize("threads", [1, 2])
+def test_full_selfplay_games_device_resident_vs_oracle(orc, threads):
     """the device-resident trainer loop (azr_selfplay_run: search, temperature pick, record, move, z back-fill,
     restart) against orc_selfplay_game with the DEVICE net called back for every evaluation: identical record
     streams (265-byte layout), move for move."""
     G, sims, B = 6, 6, 1
     P = pkg()
-    eng = P.Engine(G, blocks=B, sims=sims, dtype=P.NET_F32, max_game_rounds=36)
+    eng = P.Engine(G, blocks=B, sims=sims, dtype=P.NET_F32, max_game_rounds=36, threads=threads)
     flat = T.make_net_flat(B, seed=11, perturb_bn=True)
     eng.set_weights(flat)
     base = 4242
@@ -142,7 +147,7 @@ def test_full_selfplay_games_device_resident_vs_oracle(orc):
         C.memmove(pi, p.ctypes.data, 43 * 4)
         v[0] = float(vv[0])
 
-    cfg = T.default_settings(mcts_simulations=sims, max_game_rounds=36)
+    cfg = T.default_settings(mcts_simulations=sims, max_game_rounds=36, mcts_threads=threads)
     # records of one game are contiguous in the ring; games finish in any order: match by content
     want = {}
     for g in range(G):
