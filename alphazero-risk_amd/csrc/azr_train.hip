@@ -8,9 +8,13 @@
 //
 // Data layout (all fp32, row-major): an activation is [M = batch * 42 rows][256 channels], row = board * 42 + y * 6 + x —
 // the inference kernels' row order.  A 3x3 SAME convolution is the implicit GEMM  im2col(A) [M][9 * 256]  x  W [9 * 256][256]
-// (W = the AZRW kernel [tap][ci][co] as it lies in the flat vector) on the fp32 MFMA (v_mfma_f32_32x32x2_f32); the
-// im2col matrix is never materialised — the tile loader gathers the shifted rows.  Its two gradients are the same
-// kernel with other operand views: dW = im2col(A)^T x dY (split-K), dA = im2col-(dY) x W^T (negated taps).
+// (W = the AZRW kernel [tap][ci][co] as it lies in the flat vector); the im2col matrix is never materialised — the tile
+// loader gathers the shifted rows.  Its two gradients are the same kernel with other operand views: dW = im2col(A)^T x
+// dY (split-K), dA = im2col-(dY) x W^T (negated taps).  Arithmetic: split bf16 on v_mfma_f32_16x16x32_bf16 — an fp32
+// value is the exact sum of three bf16 parts; the forward multiplies all parts that matter (6 MFMA passes, fp32-exact
+// products, so ReLU masks and batch statistics are those of an fp32 forward), the two gradient GEMMs use two parts (3
+// passes, 1e-5 relative) — with t_gemm on the fp32 MFMA (v_mfma_f32_32x32x2_f32) kept for the stem (K = 144), odd
+// batch sizes and AZR_TRAIN_GEMM=f32.
 // Every conv output (pre-BN) and every post-activation is kept for the backward pass: 2 x 22 MB per layer at batch 512,
 // 1.8 GB for the 41 conv layers of B = 20 — sized for 288 GB of HBM, nothing is recomputed.
 // Reductions (BN statistics, bias / BN / head gradients, split-K) are two-stage and atomic-free: a step is
@@ -199,6 +203,221 @@ __global__ __launch_bounds__(256) void t_gemm(const float* __restrict__ A, int l
             for (int e = 0; e < 16; e++) {
                 const int row = m0 + wm * (32 * MI) + i * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
                 const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+                if (row < M && col < N) Cz[(size_t)row * ldc + col] = acc[i][j][e];
+            }
+}
+
+// =====================================================================================================================
+// The same GEMM in split bf16 on v_mfma_f32_16x16x32_bf16 (16x the fp32 MFMA rate).  An fp32 value is the exact sum of
+// three bf16 parts x = h + m + l (8 + 8 + 8 mantissa bits); t_split writes the parts of an operand once, and
+//   NP = 3 (forward):  C += Al*Bh + Ah*Bl + Am*Bm + Am*Bh + Ah*Bm + Ah*Bh   — every product term above 2^-24 relative:
+//                      fp32-exact products, so the ReLU masks and batch statistics match an fp32 forward;
+//   NP = 2 (backward): C += Am*Bh + Ah*Bm + Ah*Bh                           — 16 bits per factor, 1e-5 relative;
+// fp32 accumulation in both.  Tile BM x 128, k-tile 32, 4 waves as 2 x 2, LDS rows [m|n][32 + 8 pad] bf16 per part
+// (80-byte stride: an MFMA fragment's ds_read_b128 is conflict-free).  Operand views as in gt_load (MODE 0..3); a
+// mn-contiguous operand is transposed in registers (8 dword loads down k, v_perm, two 16-byte LDS writes).
+// =====================================================================================================================
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+constexpr int K3 = 32, KP3 = 40;
+struct Parts { const uint16_t* p[3]; };
+
+__device__ __forceinline__ uint32_t bf_rne_bits(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+// x[n] fp32 -> NP bf16 part arrays (n % 4 == 0)
+template <int NP>
+__global__ __launch_bounds__(256) void t_split(const float* __restrict__ x, size_t n4, uint16_t* __restrict__ p0, uint16_t* __restrict__ p1,
+                                               uint16_t* __restrict__ p2)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v4 = reinterpret_cast<const float4*>(x)[i];
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    uint32_t h[4], m[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        h[j] = bf_rne_bits(v[j]);
+        const float r1 = v[j] - __uint_as_float(h[j] << 16);
+        m[j] = bf_rne_bits(r1);
+        if (NP == 3) l[j] = bf_rne_bits(r1 - __uint_as_float(m[j] << 16));
+    }
+    reinterpret_cast<uint2*>(p0)[i] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    reinterpret_cast<uint2*>(p1)[i] = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+    if (NP == 3) reinterpret_cast<uint2*>(p2)[i] = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+// the 2B tower kernels of the flat vector -> contiguous part arrays [2B][9*256*256]
+template <int NP>
+__global__ __launch_bounds__(256) void t_split_w(const float* __restrict__ flat, uint16_t* __restrict__ p0, uint16_t* __restrict__ p1,
+                                                 uint16_t* __restrict__ p2)
+{
+    const size_t wn4 = (size_t)9 * NF * NF / 4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index inside the layer
+    if (i >= wn4) return;
+    const int l = blockIdx.y;
+    const float4 v4 = reinterpret_cast<const float4*>(flat + OFF_BLOCK0 + (size_t)l * LAYER)[i];
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    uint32_t h[4], m[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        h[j] = bf_rne_bits(v[j]);
+        const float r1 = v[j] - __uint_as_float(h[j] << 16);
+        m[j] = bf_rne_bits(r1);
+        lo[j] = bf_rne_bits(r1 - __uint_as_float(m[j] << 16));
+    }
+    const size_t o = (size_t)l * wn4 + i;
+    reinterpret_cast<uint2*>(p0)[o] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    reinterpret_cast<uint2*>(p1)[o] = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+    if (NP == 3) reinterpret_cast<uint2*>(p2)[o] = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+}
+
+// k-contiguous operand (storage [mn][k]): T rows x 32 k per tile; T / 64 16-byte loads (8 bf16) per thread and part
+template <int T, int MODE, int NP>
+__device__ __forceinline__ void sb_load_kc(const Parts& P, int ld, int mn0, int k0, int MN, int Kend, int t, uint4 (&r)[NP][T / 64])
+{
+    constexpr int V = T / 8, TPR = 32 / V;
+    const int mn = mn0 + t / TPR, k = k0 + (t % TPR) * V;
+    size_t off;
+    bool ok;
+    if constexpr (MODE == 1 || MODE == 2) {
+        const int tap = k >> 8, c = k & 255;
+        int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        if (MODE == 2) { dy = -dy; dx = -dx; }
+        const int pos = mn % NPOS, y = pos / 6 + dy, x = pos - (pos / 6) * 6 + dx;
+        ok = mn < MN && k < Kend && y >= 0 && y < 7 && x >= 0 && x < 6;
+        off = (size_t)(mn + dy * 6 + dx) * NF + c;
+    } else if constexpr (MODE == 3) {
+        off = (size_t)(k >> 8) * (NF * NF) + (size_t)mn * NF + (k & 255);
+        ok = mn < MN && k < Kend;
+    } else {
+        off = (size_t)mn * ld + k;
+        ok = mn < MN && k < Kend;
+    }
+#pragma unroll
+    for (int q = 0; q < NP; q++)
+#pragma unroll
+        for (int u = 0; u < V / 8; u++)
+            r[q][u] = ok ? reinterpret_cast<const uint4*>(P.p[q] + off)[u] : make_uint4(0u, 0u, 0u, 0u);
+}
+template <int T, int NP>
+__device__ __forceinline__ void sb_store_kc(uint16_t* S, int part_stride, int t, const uint4 (&r)[NP][T / 64])
+{
+    constexpr int V = T / 8, TPR = 32 / V;
+    const int o = (t / TPR) * KP3 + (t % TPR) * V;
+#pragma unroll
+    for (int q = 0; q < NP; q++)
+#pragma unroll
+        for (int u = 0; u < V / 8; u++) reinterpret_cast<uint4*>(S + q * part_stride + o)[u] = r[q][u];
+}
+
+// mn-contiguous operand (storage [k][mn]), 128 wide: thread = (pair of columns, group of 8 k-rows)
+template <int MODE, int NP>
+__device__ __forceinline__ void sb_load_mc(const Parts& P, int ld, int mn0, int k0, int MN, int Kend, int t, uint32_t (&r)[NP][8])
+{
+    const int mn = mn0 + 2 * (t & 63), kb = k0 + (t >> 6) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int k = kb + i;
+        bool ok = k < Kend && mn + 1 < MN;
+        size_t off;
+        if constexpr (MODE == 1) {  // col^T: k = activation row, mn = tap * 256 + c
+            const int tap = mn >> 8, c = mn & 255;
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const int pos = k % NPOS, y = pos / 6 + dy, x = pos - (pos / 6) * 6 + dx;
+            ok = ok && y >= 0 && y < 7 && x >= 0 && x < 6;
+            off = (size_t)(k + dy * 6 + dx) * NF + c;
+        } else {
+            off = (size_t)k * ld + mn;
+        }
+#pragma unroll
+        for (int q = 0; q < NP; q++) r[q][i] = ok ? *reinterpret_cast<const uint32_t*>(P.p[q] + off) : 0u;
+    }
+}
+template <int NP>
+__device__ __forceinline__ void sb_store_mc(uint16_t* S, int part_stride, int t, const uint32_t (&r)[NP][8])
+{
+    const int row = 2 * (t & 63), kg = (t >> 6) * 8;
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        uint4 c0, c1;  // the 8 k-values of the even / odd column
+        c0.x = __builtin_amdgcn_perm(r[q][1], r[q][0], 0x05040100u); c1.x = __builtin_amdgcn_perm(r[q][1], r[q][0], 0x07060302u);
+        c0.y = __builtin_amdgcn_perm(r[q][3], r[q][2], 0x05040100u); c1.y = __builtin_amdgcn_perm(r[q][3], r[q][2], 0x07060302u);
+        c0.z = __builtin_amdgcn_perm(r[q][5], r[q][4], 0x05040100u); c1.z = __builtin_amdgcn_perm(r[q][5], r[q][4], 0x07060302u);
+        c0.w = __builtin_amdgcn_perm(r[q][7], r[q][6], 0x05040100u); c1.w = __builtin_amdgcn_perm(r[q][7], r[q][6], 0x07060302u);
+        *reinterpret_cast<uint4*>(S + q * part_stride + row * KP3 + kg) = c0;
+        *reinterpret_cast<uint4*>(S + q * part_stride + (row + 1) * KP3 + kg) = c1;
+    }
+}
+
+template <bool A_MCONTIG, bool B_KCONTIG, int BM, int AMODE, int BMODE, int NP>
+__global__ __launch_bounds__(256) void t_gemm_sb(Parts A, int lda, Parts B, int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
+                                                 int kchunk, size_t strideCz)
+{
+    static_assert(!A_MCONTIG || BM == 128, "the mn-contiguous loader is 128 wide");
+    constexpr int MI = BM / 32;  // 16-row MFMA tiles per wave along m
+    constexpr int SA = BM * KP3, SB = GT * KP3;
+    __shared__ __attribute__((aligned(16))) uint16_t As[NP * SA];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[NP * SB];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * GT;
+    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 rak[NP][BM / 64], rbk[NP][GT / 64];
+    uint32_t ram[NP][8], rbm[NP][8];
+    auto loadA = [&](int k0) {
+        if constexpr (A_MCONTIG) sb_load_mc<AMODE, NP>(A, lda, m0, k0, M, kend, t, ram);
+        else sb_load_kc<BM, AMODE, NP>(A, lda, m0, k0, M, kend, t, rak);
+    };
+    auto loadB = [&](int k0) {
+        if constexpr (B_KCONTIG) sb_load_kc<GT, BMODE, NP>(B, ldb, n0, k0, N, kend, t, rbk);
+        else sb_load_mc<BMODE, NP>(B, ldb, n0, k0, N, kend, t, rbm);
+    };
+    loadA(kbeg);
+    loadB(kbeg);
+    const int fo = (lane & 15) * KP3 + (lane >> 4) * 8;  // this lane's fragment offset inside a 16-row tile
+    for (int k0 = kbeg; k0 < kend; k0 += K3) {
+        __syncthreads();
+        if constexpr (A_MCONTIG) sb_store_mc<NP>(As, SA, t, ram); else sb_store_kc<BM, NP>(As, SA, t, rak);
+        if constexpr (B_KCONTIG) sb_store_kc<GT, NP>(Bs, SB, t, rbk); else sb_store_mc<NP>(Bs, SB, t, rbm);
+        __syncthreads();
+        if (k0 + K3 < kend) { loadA(k0 + K3); loadB(k0 + K3); }
+        s16x8 b[NP][4];
+#pragma unroll
+        for (int q = 0; q < NP; q++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[q][j] = *reinterpret_cast<const s16x8*>(Bs + q * SB + (wn * 64 + j * 16) * KP3 + fo);
+#pragma unroll
+        for (int i = 0; i < MI; i++) {
+            s16x8 a[NP];
+#pragma unroll
+            for (int q = 0; q < NP; q++) a[q] = *reinterpret_cast<const s16x8*>(As + q * SA + (wm * (BM / 2) + i * 16) * KP3 + fo);
+#define SB_MFMA(qa, qb) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[qa]), __builtin_bit_cast(bf16x8, b[qb][j]), acc[i][j], 0, 0, 0)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {  // smallest terms first
+                if constexpr (NP == 3) { SB_MFMA(2, 0); SB_MFMA(0, 2); SB_MFMA(1, 1); }
+                SB_MFMA(1, 0);
+                SB_MFMA(0, 1);
+                SB_MFMA(0, 0);
+            }
+#undef SB_MFMA
+        }
+    }
+    float* Cz = C + (size_t)blockIdx.z * strideCz;
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int row = m0 + wm * (BM / 2) + i * 16 + 4 * (lane >> 4) + e;
+                const int col = n0 + wn * 64 + j * 16 + (lane & 15);
                 if (row < M && col < N) Cz[(size_t)row * ldc + col] = acc[i][j][e];
             }
 }
@@ -787,6 +1006,9 @@ __global__ void t_adam(float* __restrict__ w, const float* __restrict__ g, float
 // =====================================================================================================================
 // host
 // =====================================================================================================================
+// conv GEMM arithmetic: split bf16 (default; 6-pass forward, 3-pass backward) or the fp32 MFMA (AZR_TRAIN_GEMM=f32)
+bool g_gemm_bf16x3 = true;
+
 struct TrainCtx {
     int BS = 0, blocks = 0, M = 0, L = 0, R = 0, nz = 0, kchunk = 0;
     size_t count = 0;
@@ -800,6 +1022,7 @@ struct TrainCtx {
     float* sums = nullptr;                   // [2][256]
     double* part = nullptr;                  // [R][2*NG][256]
     float* wpart = nullptr;                  // split-K partials [nz][KC][256]
+    uint16_t *ap[3] = {nullptr, nullptr, nullptr}, *dyp[2] = {nullptr, nullptr}, *wp[3] = {nullptr, nullptr, nullptr};  // bf16 parts
     float *pv0 = nullptr, *dpv = nullptr, *hstat = nullptr, *fpi = nullptr, *fv = nullptr, *h1 = nullptr, *vout = nullptr,
           *prob = nullptr, *lossb = nullptr, *hpart = nullptr, *cpart = nullptr, *loss = nullptr;
     uint8_t* rec = nullptr;
@@ -839,6 +1062,7 @@ void ctx_free(TrainCtx* c)
 int ctx_ensure(azr_engine* h, int BS)
 {
     TrainCtx* c = ctx_of(h);
+    if (const char* e = getenv("AZR_TRAIN_GEMM")) g_gemm_bf16x3 = strcmp(e, "f32") != 0;
     if (c && c->BS == BS) return AZR_OK;
     // a different batch size rebuilds the activation slabs but keeps the optimiser state
     std::vector<float> keep_m, keep_v;
@@ -859,7 +1083,7 @@ int ctx_ensure(azr_engine* h, int BS)
     c->count = net_param_count(B);
     // split-K of the weight-gradient GEMM (36 output tiles of 128 x 128): as many slices as keep <= 2 blocks per CU
     c->nz = std::max(1, std::min(512 / ((KC / GT) * (NF / GT)), (c->M + 1023) / 1024));
-    c->kchunk = (((c->M + c->nz - 1) / c->nz) + GK - 1) / GK * GK;
+    c->kchunk = (((c->M + c->nz - 1) / c->nz) + K3 - 1) / K3 * K3;
     c->step = keep_step;
     const size_t M = c->M, act = M * NF;
     TRY(dalloc(h, c, &c->g, c->count)); TRY(dalloc(h, c, &c->m, c->count)); TRY(dalloc(h, c, &c->v, c->count));
@@ -872,6 +1096,8 @@ int ctx_ensure(azr_engine* h, int BS)
     TRY(dalloc(h, c, &c->sums, (size_t)2 * NF));
     TRY(dalloc(h, c, &c->part, (size_t)c->R * 2 * NG * NF));
     TRY(dalloc(h, c, &c->wpart, (size_t)c->nz * KC * NF));
+    for (int q = 0; q < 3; q++) { TRY(dalloc(h, c, &c->ap[q], act)); TRY(dalloc(h, c, &c->wp[q], (size_t)2 * B * KC * NF)); }
+    for (int q = 0; q < 2; q++) TRY(dalloc(h, c, &c->dyp[q], act));
     TRY(dalloc(h, c, &c->pv0, M * 4)); TRY(dalloc(h, c, &c->dpv, M * 4)); TRY(dalloc(h, c, &c->hstat, (size_t)8));
     TRY(dalloc(h, c, &c->fpi, (size_t)BS * 84)); TRY(dalloc(h, c, &c->fv, (size_t)BS * 42)); TRY(dalloc(h, c, &c->h1, (size_t)BS * 256));
     TRY(dalloc(h, c, &c->vout, (size_t)BS)); TRY(dalloc(h, c, &c->prob, (size_t)BS * 43)); TRY(dalloc(h, c, &c->lossb, (size_t)BS * 2));
@@ -917,6 +1143,15 @@ void gemm(hipStream_t st, const float* A, int lda, const float* B, int ldb, floa
                        C, ldc, M, N, K, kchunk, strideCz);
 }
 
+template <bool A_MCONTIG, bool B_KCONTIG, int BM, int AMODE, int BMODE, int NP>
+void gemm_sb(hipStream_t st, Parts A, int lda, Parts B, int ldb, float* C, int ldc, int M, int N, int K, int nz = 1, int kchunk = 0,
+             size_t strideCz = 0)
+{
+    if (nz == 1) kchunk = K;
+    hipLaunchKernelGGL((t_gemm_sb<A_MCONTIG, B_KCONTIG, BM, AMODE, BMODE, NP>), dim3((N + GT - 1) / GT, (M + BM - 1) / BM, nz), dim3(256), 0,
+                       st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, strideCz);
+}
+
 inline dim3 grid1(size_t n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 // one optimiser step on the minibatch already gathered into c->in88 / pit / zt
@@ -926,7 +1161,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     const int M = c->M, B = c->blocks, R = c->R, BS = c->BS;
     float* w = h->net.d_flat;
     float* g = c->g;
-    const size_t act = (size_t)M * NF;
+    const size_t act = (size_t)M * NF, wn_ = (size_t)KC * NF;
     const size_t hh = OFF_BLOCK0 + (size_t)2 * B * LAYER;
     float* hp = w + hh;
     float* gh = g + hh;
@@ -935,6 +1170,12 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     auto Yl = [&](int l) { return c->Y + act * l; };
     auto Al = [&](int l) { return c->A + act * l; };
     const unsigned g4 = (unsigned)((act / 4 + 255) / 256);
+    const bool sb = g_gemm_bf16x3 && M % K3 == 0;  // split-bf16 conv GEMMs (the stem, K = 144, stays on the fp32 MFMA)
+    auto Wp = [&](int l) {
+        const size_t o = (size_t)(l - 1) * KC * NF;
+        return Parts{{c->wp[0] + o, c->wp[1] + o, c->wp[2] + o}};
+    };
+    if (sb) hipLaunchKernelGGL((t_split_w<3>), dim3((unsigned)((wn_ / 4 + 255) / 256), 2 * B), dim3(256), 0, st, w, c->wp[0], c->wp[1], c->wp[2]);
 
     // ---------------- forward, training mode
     hipLaunchKernelGGL(t_planes, grid1((size_t)M * SIN, 256), dim3(256), 0, st, c->in88, M, c->X0);
@@ -947,7 +1188,10 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     for (int l = 1; l < c->L; l++) {
         float* bn = Wl(l) + (size_t)9 * NF * NF;
         const float* S = (l % 2 == 0) ? Al(l - 2) : nullptr;  // second conv of a block adds the block input
-        gemm<false, false, 64, 1, 0>(st, Al(l - 1), KC, Wl(l), NF, Yl(l), NF, M, NF, KC);  // conv = implicit im2col x W
+        if (sb) {  // conv = implicit im2col x W, 6-pass split bf16 (fp32-exact products)
+            hipLaunchKernelGGL((t_split<3>), dim3(g4), dim3(256), 0, st, Al(l - 1), act / 4, c->ap[0], c->ap[1], c->ap[2]);
+            gemm_sb<false, false, 64, 1, 0, 3>(st, Parts{{c->ap[0], c->ap[1], c->ap[2]}}, KC, Wp(l), NF, Yl(l), NF, M, NF, KC);
+        } else gemm<false, false, 64, 1, 0>(st, Al(l - 1), KC, Wl(l), NF, Yl(l), NF, M, NF, KC);
         hipLaunchKernelGGL((t_bn_stats<false>), dim3(R), dim3(1024), 0, st, Yl(l), M, c->part);
         hipLaunchKernelGGL((t_bn_finalize<false>), dim3(1), dim3(1024), 0, st, c->part, R, (double)M, c->mean + l * NF, c->istd + l * NF, bn);
         hipLaunchKernelGGL((t_bn_apply<false>), dim3(g4), dim3(256), 0, st, Yl(l), c->mean + l * NF, c->istd + l * NF, bn, S, Al(l), M);
@@ -965,7 +1209,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     hipLaunchKernelGGL(t_head_conv_bwd, dim3(R), dim3(256), 0, st, H, c->dpv, hp, M, c->G, c->cpart);
     hipLaunchKernelGGL(t_head_conv_bwd_finalize, dim3(1), dim3(256), 0, st, c->cpart, R, gh);
     const float invM = 1.0f / (float)M;
-    const size_t wn = (size_t)KC * NF;
+    const size_t wn = wn_;
     for (int l = c->L - 1; l >= 1; l--) {
         // gradient w.r.t. this layer's post-activation output: G for the second conv of a block, DT for the first
         const bool second = (l % 2 == 0);
@@ -977,11 +1221,17 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         hipLaunchKernelGGL((t_bn_bwd_apply<false>), dim3(g4), dim3(256), 0, st, dOut, Al(l), Yl(l), c->mean + l * NF, c->istd + l * NF, bn, c->sums,
                            invM, c->dY, second ? c->DS : (float*)nullptr, M);
         // dW = col(input)^T x dY  (implicit im2col, split-K over the M rows)
-        gemm<true, false, 128, 1, 0>(st, Al(l - 1), KC, c->dY, NF, c->wpart, NF, KC, NF, M, c->nz, c->kchunk, wn);
+        if (sb) {
+            hipLaunchKernelGGL((t_split<2>), dim3(g4), dim3(256), 0, st, Al(l - 1), act / 4, c->ap[0], c->ap[1], (uint16_t*)nullptr);
+            hipLaunchKernelGGL((t_split<2>), dim3(g4), dim3(256), 0, st, c->dY, act / 4, c->dyp[0], c->dyp[1], (uint16_t*)nullptr);
+            gemm_sb<true, false, 128, 1, 0, 2>(st, Parts{{c->ap[0], c->ap[1], nullptr}}, KC, Parts{{c->dyp[0], c->dyp[1], nullptr}}, NF, c->wpart,
+                                               NF, KC, NF, M, c->nz, c->kchunk, wn);
+        } else gemm<true, false, 128, 1, 0>(st, Al(l - 1), KC, c->dY, NF, c->wpart, NF, KC, NF, M, c->nz, c->kchunk, wn);
         hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, c->nz, wn, Gl(l));
         // d(input) = transposed conv of dY with W: the same implicit GEMM with negated taps and W read as [tap][co] x [ci]
         float* dIn = second ? c->DT : c->G;
-        gemm<false, true, 64, 2, 3>(st, c->dY, KC, Wl(l), NF, dIn, NF, M, NF, KC);
+        if (sb) gemm_sb<false, true, 64, 2, 3, 2>(st, Parts{{c->dyp[0], c->dyp[1], nullptr}}, KC, Wp(l), NF, dIn, NF, M, NF, KC);
+        else gemm<false, true, 64, 2, 3>(st, c->dY, KC, Wl(l), NF, dIn, NF, M, NF, KC);
         if (!second) hipLaunchKernelGGL(t_add, dim3(g4), dim3(256), 0, st, dIn, c->DS, act / 4);  // + shortcut gradient
     }
     {   // stem: parameters only

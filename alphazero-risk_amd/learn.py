@@ -126,8 +126,9 @@ def learn(a, log=print):
     os.makedirs("log", exist_ok=True)
     os.makedirs("checkpoints", exist_ok=True)
     dtype = P.NET_BF16 if a.dtype == "bf16" else P.NET_F32
-    gen = P.Engine(a.gpu_games, blocks=a.blocks, sims=a.mcts, dtype=dtype, device=a.device)
-    new = P.Engine(a.gpu_games, blocks=a.blocks, sims=a.mcts, dtype=dtype, device=a.device)
+    t = getattr(a, "t", 2)
+    gen = P.Engine(a.gpu_games, blocks=a.blocks, sims=a.mcts, dtype=dtype, device=a.device, threads=t)
+    new = P.Engine(a.gpu_games, blocks=a.blocks, sims=a.mcts, dtype=dtype, device=a.device, threads=t)
     latest, best = "checkpoints/latest-checkpoint.bin", "checkpoints/best-checkpoint.bin"
     for e in (new, gen):  # loadCheckpoint: missing => init + save (alphazero_nn.cpp:197-202)
         if os.path.exists(latest):
@@ -211,6 +212,7 @@ def main():
     ap.add_argument("--ti", type=int, default=10000)      # TRAIN_ITERATIONS
     ap.add_argument("--tg", type=int, default=1000)       # TRAIN_ITERATION_GAMES
     ap.add_argument("--mcts", type=int, default=32)
+    ap.add_argument("-t", type=int, default=2)            # THREADS_PER_MCTS
     ap.add_argument("--gpu-games", type=int, default=256)
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("-e", type=int, default=10)           # EPOCHS
