@@ -11,6 +11,12 @@ checkpoint names (checkpoints/{latest,best}-checkpoint.bin, checkpoint-iter-N.bi
 
     python -m alphazero-risk_amd.learn ...     is not importable as a module name with a hyphen; run
     python alphazero-risk_amd/learn.py --ti 2 --tg 256 --mcts 100 --gpu-games 256 --blocks 20 --cg 100
+
+Multi-GPU (BASELINE configs[4]): one process per GPU under torchrun,
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 alphazero-risk_amd/learn.py ...
+Self-play, the arena and the benchmark games are sharded over the ranks with no collective inside them; the exchange
+steps of an iteration are: all_gather of the new (s, pi, z) records, broadcast of the trained weights from rank 0 (the
+reference trains on GPU 0 and hands the weights over through temp.bin), all_reduce of the six GameResults counters.
 """
 import argparse
 import importlib
@@ -24,6 +30,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 P = importlib.import_module("alphazero-risk_amd")
 train_mod = importlib.import_module("alphazero-risk_amd.train")
+shard_mod = importlib.import_module("alphazero-risk_amd.shard")
 
 
 # ---- host-side pieces of Game (game/game.cpp) for the two-net arena ---------------------------------------------------
@@ -122,11 +129,21 @@ def run_arena(eng, p1, p2, games, mirror, seed):
     return eng.arena_results()
 
 
-def learn(a, log=print):
+def reduce_results(gr, dist, dev):
+    """GameResults::add over ranks"""
+    flat = dict(count=gr["count"], draw=gr["draw"], w0=gr["win"][0], w1=gr["win"][1], s0=gr["win_and_started"][0],
+                s1=gr["win_and_started"][1])
+    r = shard_mod.reduce_counters(flat, dist, device=dev)
+    return dict(count=r["count"], draw=r["draw"], win=[r["w0"], r["w1"]], win_and_started=[r["s0"], r["s1"]])
+
+
+def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
     os.makedirs("log", exist_ok=True)
     os.makedirs("checkpoints", exist_ok=True)
     dtype = P.NET_BF16 if a.dtype == "bf16" else P.NET_F32
     t = getattr(a, "t", 2)
+    if rank != 0:
+        log = lambda *_: None   # noqa: E731  (rank 0 reports)
     gen = P.Engine(a.gpu_games, blocks=a.blocks, sims=a.mcts, dtype=dtype, device=a.device, threads=t)
     new = P.Engine(a.gpu_games, blocks=a.blocks, sims=a.mcts, dtype=dtype, device=a.device, threads=t)
     latest, best = "checkpoints/latest-checkpoint.bin", "checkpoints/best-checkpoint.bin"
@@ -135,30 +152,40 @@ def learn(a, log=print):
             e.load(latest)
         else:
             e.init_random(20260002)
-            e.save(latest)
+            if rank == 0:
+                e.save(latest)
+    if dist is not None:
+        dist.barrier()
     trainer = None
     if getattr(a, "trainer", "native") == "torch":
         trainer = train_mod.Trainer(a.blocks, new.get_weights(), device=f"cuda:{a.device}", batch_size=a.bs, seed=a.seed)
     shuffle_state = a.seed % 2147483646 + 1   # raw minstd_rand0 state standing in for the reference's global RNG
     records = np.zeros((0, 265), np.uint8)
     old_game_index = 0
-    imp_log = open("log/azr-improvement-log.txt", "a")
-    bench_log = open("log/azr-benchmark-log.txt", "a")
-    nn_log = open("log/azr-nn-training-log.txt", "a")
+    sink = "/dev/null" if rank else None
+    imp_log = open(sink or "log/azr-improvement-log.txt", "a")
+    bench_log = open(sink or "log/azr-benchmark-log.txt", "a")
+    nn_log = open(sink or "log/azr-nn-training-log.txt", "a")
     summary = []
     for it in range(a.ti):
         log(f"Train iteration {it}")
         # ---- generateTrainData (alphazero_trainer.cpp:36-78)
         t0 = time.time()
-        gen.selfplay_start((a.seed + it * 65536 * a.gpu_games) & 0xFFFFFFFF)
-        new_recs = []
-        while True:
+        share = shard_mod.split_count(a.tg, world, rank)   # one self-play shard per GPU (alphazero_trainer.cpp:41-57)
+        gen.selfplay_start(shard_mod.rank_base_seed((a.seed + it * 65536 * a.gpu_games) & 0xFFFFFFFF, rank))
+        new_recs = [np.zeros((0, 265), np.uint8)]
+        c = gen.counters()
+        while share > 0:
             gen.selfplay_run(4 * (a.mcts + 2))
             c = gen.counters()
             new_recs.append(gen.drain())
-            if c["games_finished"] >= a.tg:
+            if c["games_finished"] >= share:
                 break
         new_recs = np.concatenate(new_recs)
+        if dist is not None:   # the one exchange step of data generation: records of all shards, in rank order
+            import torch
+            new_recs = shard_mod.gather_records(torch.from_numpy(new_recs).to(cdev), dist).cpu().numpy()
+            c = shard_mod.reduce_counters({k: c[k] for k in ("games_finished", "simulations")}, dist, device=cdev)
         dt = time.time() - t0
         log(f"Generated {len(new_recs)} new samples for total {len(records) + len(new_recs)}  "
             f"[{c['games_finished']} games, {c['simulations'] / dt:.0f} simulations/s, {c['games_finished'] / dt:.2f} games/s]")
@@ -166,13 +193,19 @@ def learn(a, log=print):
         records, old_game_index = trim_old_examples(records, old_game_index, a.s, 16384 * a.bs)
         # ---- trainGroup->train (alphazero_gpu_cluster.cpp:221-231)
         t0 = time.time()
-        if trainer is not None:
-            hist = trainer.train(records, a.e, nn_log)
-            new.set_weights(trainer.flat())
-        else:
-            hist, shuffle_state = new.train(records, a.e, batch_size=a.bs, rng_state=shuffle_state)
-            hist = [h for h in hist if not np.isnan(h[0])]
-            nn_log.write("".join(f"{lp}, {lv}, " for lp, lv in hist) + "\n"); nn_log.flush()
+        hist = []
+        if rank == 0:   # AlphaZeroNNGroup::train: the first GPU trains (alphazero_gpu_cluster.cpp:221-231)
+            if trainer is not None:
+                hist = trainer.train(records, a.e, nn_log)
+                new.set_weights(trainer.flat())
+            else:
+                hist, shuffle_state = new.train(records, a.e, batch_size=a.bs, rng_state=shuffle_state)
+                hist = [h for h in hist if not np.isnan(h[0])]
+                nn_log.write("".join(f"{lp}, {lv}, " for lp, lv in hist) + "\n"); nn_log.flush()
+        if dist is not None:   # ... and the others receive its weights
+            w = shard_mod.broadcast_flat(new.get_weights(), dist, src=0, device=cdev)
+            if rank != 0:
+                new.set_weights(w)
         steps = a.e * (len(records) // a.bs)
         if hist:
             log(f"Loss Policy / Value: {hist[-1][0]:f} / {hist[-1][1]:f}   [{steps} steps, {1e3 * (time.time() - t0) / max(steps, 1):.1f} ms/step]")
@@ -180,15 +213,23 @@ def learn(a, log=print):
         improved = True
         gr = None
         if a.cg > 0:
-            gr = arena_two_nets(new, gen, a.cg, True, a.seed + 7919 * (it + 1))
+            gr = arena_two_nets(new, gen, 2 * shard_mod.split_count(a.cg // 2, world, rank), True,
+                                shard_mod.rank_base_seed(a.seed + 7919 * (it + 1), rank))
+            if dist is not None:
+                gr = reduce_results(gr, dist, cdev)
             imp_log.write(f"{it},{gr_str(gr)}\n"); imp_log.flush()
             improved = is_model_improved(gr, a.ct)
         if improved:
             log("Model improved")
-            new.save(best); new.save(f"checkpoints/checkpoint-iter-{it}.bin")
-            gen.load(best)
-            r = run_arena(gen, P.PLAYER_ALPHAZERO, P.PLAYER_RANDOM, 10, True, a.seed + 11)
-            s = run_arena(gen, P.PLAYER_ALPHAZERO, P.PLAYER_SCRIPT, 100, True, a.seed + 13)
+            if rank == 0:
+                new.save(best); new.save(f"checkpoints/checkpoint-iter-{it}.bin")
+            gen.set_weights(new.get_weights())   # generateGroup->loadCheckpoint(best): every rank already holds them
+            r = run_arena(gen, P.PLAYER_ALPHAZERO, P.PLAYER_RANDOM, 2 * shard_mod.split_count(5, world, rank), True,
+                          shard_mod.rank_base_seed(a.seed + 11, rank))
+            s = run_arena(gen, P.PLAYER_ALPHAZERO, P.PLAYER_SCRIPT, 2 * shard_mod.split_count(50, world, rank), True,
+                          shard_mod.rank_base_seed(a.seed + 13, rank))
+            if dist is not None:
+                r, s = reduce_results(r, dist, cdev), reduce_results(s, dist, cdev)
             bench_log.write(f"{it},{gr_str(r)}, {gr_str(s)}\n"); bench_log.flush()
             log(f"Model benchmark: vs Random {r['win'][0]}/{r['count']}, vs Script {s['win'][0]}/{s['count']}")
             old_game_index = max(len(records) - 1, 0)   # updateOldGamesIndex
@@ -199,10 +240,11 @@ def learn(a, log=print):
                 trainer.load_flat(new.get_weights())
         summary.append(dict(iteration=it, samples=len(records), losses=hist, arena=gr, improved=improved))
     # saveTrainingSamples (reference writer layout: 8-byte count + 265-byte records)
-    os.makedirs("data", exist_ok=True)
-    with open("data/training_samples.bin", "wb") as f:
-        f.write(np.uint64(len(records)).tobytes())
-        f.write(records.tobytes())
+    if rank == 0:
+        os.makedirs("data", exist_ok=True)
+        with open("data/training_samples.bin", "wb") as f:
+            f.write(np.uint64(len(records)).tobytes())
+            f.write(records.tobytes())
     gen.close(); new.close()
     return summary
 
@@ -224,7 +266,25 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--trainer", default="native", choices=["native", "torch"])
-    learn(ap.parse_args())
+    a = ap.parse_args()
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        learn(a)
+        return
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get("AZR_LEARN_BACKEND", "nccl")   # "gloo": rehearsal of the N > 1 path on fewer GPUs than ranks
+    ndev = torch.cuda.device_count()
+    a.device = local % max(ndev, 1)
+    if backend == "nccl":
+        torch.cuda.set_device(a.device)   # torch's HIP runtime first, then the C-ABI library's
+        torch.cuda.init()
+    dist.init_process_group(backend)
+    try:
+        learn(a, dist=dist, rank=rank, world=world, cdev=f"cuda:{a.device}" if backend == "nccl" else "cpu")
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -49,6 +49,24 @@ def reduce_counters(counters, dist=None, device="cpu"):
     return {k: int(v) for k, v in zip(keys, t.tolist())}
 
 
+def split_count(total, world, rank):
+    """rank's share of `total` units (games, pairs): total // world, the first total % world ranks one more"""
+    return total // world + (1 if rank < total % world else 0)
+
+
+def broadcast_flat(flat, dist=None, src=0, device="cpu"):
+    """the trained AZRW vector from the training rank to every rank (RCCL broadcast over xGMI; the reference hands the
+    weights to the other GPUs through checkpoints/temp.bin, alphazero_gpu_cluster.cpp:221-231).  flat: float32 ndarray,
+    same size on every rank; returns the received ndarray."""
+    import torch
+
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return flat
+    t = torch.from_numpy(np.ascontiguousarray(flat, np.float32)).to(device)
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
 def device_records_to_torch(ptr, n, device):
     """copy n packed records from the engine's device ring (raw pointer) into a torch uint8 tensor on `device`"""
     import ctypes as C

@@ -78,3 +78,31 @@ def test_one_learn_iteration_end_to_end(tmp_path, trainer):
     raw = open(tmp_path / "data/training_samples.bin", "rb").read()
     n = int(np.frombuffer(raw[:8], np.uint64)[0])
     assert len(raw) == 8 + n * 265 and n == out[0]["samples"]
+
+
+@pytest.mark.gpu
+def test_two_rank_learn_iteration(tmp_path):
+    """the N > 1 learn path (BASELINE configs[4]) rehearsed with 2 ranks on this box's one GPU over gloo: sharded
+    self-play, all_gather of the records, training on rank 0, weight broadcast, sharded arena + benchmark with reduced
+    GameResults; rank 0 writes the reference's files"""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, AZR_LEARN_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "alphazero-risk_amd", "learn.py"), "--ti", "1", "--tg", "8", "--mcts", "6",
+           "--gpu-games", "8", "--blocks", "1", "-e", "2", "--bs", "64", "--cg", "8", "--ct", "0"]
+    r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-2000:]
+    assert "Model improved" in r.stdout and "Loss Policy / Value" in r.stdout
+    imp = open(tmp_path / "log/azr-improvement-log.txt").read().strip().split(",")
+    assert imp[0] == "0" and len(imp) == 4
+    d, w0, w1 = int(imp[1]), int(imp[2].split("/")[0]), int(imp[3].split("/")[0])
+    assert d + w0 + w1 == 8                                  # 2 ranks x 2 pairs
+    bench = open(tmp_path / "log/azr-benchmark-log.txt").read().strip()
+    nums = [int(x.split("/")[0]) for x in bench.replace(" ", "").split(",")[1:]]
+    assert nums[0] + nums[1] + nums[2] == 10 and nums[3] + nums[4] + nums[5] == 100
+    raw = open(tmp_path / "data/training_samples.bin", "rb").read()
+    n = int(np.frombuffer(raw[:8], np.uint64)[0])
+    assert len(raw) == 8 + n * 265 and n > 500

@@ -33,6 +33,10 @@ def _worker(rank, world, port, q):
     allr = shard.gather_records(recs, dist)
     empty = shard.gather_records(torch.zeros((0, 265), dtype=torch.uint8) if rank == 0 else recs, dist)
     tot = shard.reduce_counters({"simulations": 10 * (rank + 1), "games_finished": rank}, dist)
+    # the learn loop's weight hand-over: rank 0's vector reaches every rank
+    flat = np.full(1000, float(rank + 1), np.float32) + np.arange(1000, dtype=np.float32)
+    got = shard.broadcast_flat(flat, dist, src=0)
+    assert (got == np.float32(1.0) + np.arange(1000, dtype=np.float32)).all()
     q.put((rank, recs.numpy(), allr.numpy(), empty.shape[0], tot, shard.rank_base_seed(20260001, rank)))
     dist.barrier()
     dist.destroy_process_group()
@@ -57,3 +61,12 @@ def test_gather_records_world2_gloo():
         assert res[r][4] == {"simulations": 30, "games_finished": 1}
     # seed ranges of different ranks cannot collide for < 2^24 games per slot-stream
     assert res[1][5] - res[0][5] == 1 << 24
+
+
+def test_split_count_covers_the_total():
+    sys.path.insert(0, ROOT)
+    shard = importlib.import_module("alphazero-risk_amd.shard")
+    for total in (0, 1, 5, 50, 1000):
+        for world in (1, 2, 3, 8):
+            parts = [shard.split_count(total, world, r) for r in range(world)]
+            assert sum(parts) == total and max(parts) - min(parts) <= 1 and parts == sorted(parts, reverse=True)
