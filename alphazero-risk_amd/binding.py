@@ -34,7 +34,7 @@ class GameResults(C.Structure):
         return dict(count=self.count, draw=self.draw, win=list(self.win), win_and_started=list(self.win_and_started))
 
 
-PLAYER_ALPHAZERO, PLAYER_SCRIPT, PLAYER_RANDOM = 0, 1, 2
+PLAYER_ALPHAZERO, PLAYER_SCRIPT, PLAYER_RANDOM, PLAYER_ALPHAZERO_B = 0, 1, 2, 3
 
 
 class Counters(C.Structure):
@@ -66,6 +66,7 @@ EXPORTS = [
     "azr_mcts_apply", "azr_mcts_root_stats", "azr_mcts_policy", "azr_mcts_pick", "azr_selfplay_start", "azr_selfplay_run",
     "azr_selfplay_counters", "azr_samples_drain", "azr_samples_device_view", "azr_profile_last_run",
     "azr_device_synchronize", "azr_arena_start", "azr_arena_run", "azr_arena_results", "azr_arena_log",
+    "azr_arena_set_opponent_net", "azr_arena_collect_samples",
 ]
 
 
@@ -116,6 +117,8 @@ def load_library():
         L.azr_engine_make_moves.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.azr_arena_start.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
         L.azr_arena_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.azr_arena_set_opponent_net.argtypes = [C.c_void_p, C.c_void_p]
+        L.azr_arena_collect_samples.argtypes = [C.c_void_p, C.c_int]
         L.azr_arena_results.argtypes = [C.c_void_p, C.c_void_p]
         L.azr_arena_log.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -352,6 +355,14 @@ class Engine:
     # ---- arena (GameGroup::playGames)
     def arena_start(self, player1, player2, games, per_slot_cap=0, mirror=True, base_seed=20260001):
         self._chk(self.L.azr_arena_start(self.h, player1, player2, games, per_slot_cap, int(mirror), base_seed))
+
+    def arena_set_opponent(self, other):
+        """the network of PLAYER_ALPHAZERO_B = `other`'s (an Engine on the same device, or None to detach)"""
+        self._chk(self.L.azr_arena_set_opponent_net(self.h, other.h if other is not None else None))
+        self._opponent = other   # keep it alive
+
+    def arena_collect_samples(self, on=True):
+        self._chk(self.L.azr_arena_collect_samples(self.h, int(on)))
 
     def arena_run(self, passes):
         fin = C.c_int(0)

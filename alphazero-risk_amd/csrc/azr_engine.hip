@@ -36,6 +36,27 @@ __device__ __forceinline__ Tree tree_of(const Dev& E, int g)
     return t;
 }
 
+// the opponent AlphaZero player's tree of game g (two-net arena)
+__device__ __forceinline__ Tree tree2_of(const Dev& E, int g)
+{
+    Tree t = tree_of(E, g);
+    t.nodes = E.nodes2 + (size_t)g * E.C * NODE_BYTES;
+    t.touch = E.touch2 + (size_t)g * E.C;
+    t.nhash = E.nhash2 + (size_t)g * E.C;
+    t.table = E.table2 + (size_t)g * E.H;
+    t.freel = E.freel2 + (size_t)g * E.C;
+    return t;
+}
+// tree 2's allocator / trim state lives outside the (full) Ctl line; it is swapped into the Ctl fields the tree
+// functions use while that tree is being worked on
+struct TreeCtl { uint32_t search_id, nfree, hiwater; };
+__device__ __forceinline__ void swap_tree_ctl(Ctl& c, TreeCtl& x)
+{
+    uint32_t a = c.search_id, b = c.nfree, d = c.hiwater;
+    c.search_id = x.search_id; c.nfree = x.nfree; c.hiwater = x.hiwater;
+    x.search_id = a; x.nfree = b; x.hiwater = d;
+}
+
 __device__ __forceinline__ void ctl_load(Ctl& c, const Ctl* src)
 {
     const uint32_t* p = reinterpret_cast<const uint32_t*>(src);
@@ -48,6 +69,7 @@ __device__ __forceinline__ void ctl_load(Ctl& c, const Ctl* src)
     c.search_active = rdl(w, 20); c.slot_games = rdl(w, 21); c.dup_dropped = rdl(w, 22);
 #pragma unroll
     for (int k = 0; k < MAX_THREADS; k++) c.plen[k] = rdl(w, 23 + k);
+    c.search_tree = rdl(w, 31);
 }
 // c.plen[k] with a wave-uniform runtime k, without indexing the register array
 __device__ __forceinline__ uint32_t plen_get(const Ctl& c, int k)
@@ -81,7 +103,8 @@ __device__ __forceinline__ void ctl_store(const Ctl& c, Ctl* dst)
     w = l == 22 ? c.dup_dropped : w;
 #pragma unroll
     for (int k = 0; k < MAX_THREADS; k++) w = l == 23u + k ? c.plen[k] : w;
-    if (l < 23 + MAX_THREADS) reinterpret_cast<uint32_t*>(dst)[l] = w;
+    w = l == 31 ? c.search_tree : w;
+    if (l < 32) reinterpret_cast<uint32_t*>(dst)[l] = w;
 }
 
 // ================================================================================================
@@ -533,7 +556,16 @@ __global__ __launch_bounds__(64) void k_arena_step(Dev E)
         sp[1].land_from = rfl(sp[1].land_from); sp[1].attack_from_army = rfl(sp[1].attack_from_army);
     }
     StepCount k;
-    consume_pending(E, g, t, c, k);
+    // two-net arena: the opponent AlphaZero player's own tree and its allocator state
+    const bool two = E.nodes2 != nullptr;
+    const Tree t2 = two ? tree2_of(E, g) : t;
+    TreeCtl x2 = {0, 0, 0};
+    if (two) {
+        const uint32_t w = E.tctl2[(size_t)g * 4 + (lane_id() & 3u)];
+        x2.search_id = rdl(w, 0); x2.nfree = rdl(w, 1); x2.hiwater = rdl(w, 2);
+    }
+    if (c.search_tree) { swap_tree_ctl(c, x2); consume_pending(E, g, t2, c, k); swap_tree_ctl(c, x2); }
+    else consume_pending(E, g, t, c, k);
     for (;;) {
         if (c.arena_state == 0) {  // Game::newGame (game.cpp:170-191) for the next Game::playGames(1)
             if (c.pair_phase == 0) {  // Counter::hasNext(2) (game.cpp:14-26)
@@ -555,6 +587,8 @@ __global__ __launch_bounds__(64) void k_arena_step(Dev E)
                 ws_store(root, E.prev_start + (size_t)g * GREC);
             }
             tree_clear(t, c);  // AlphaZeroPlayer::newGame
+            if (two) { swap_tree_ctl(c, x2); tree_clear(t2, c); swap_tree_ctl(c, x2); }
+            c.nsamples = 0;
             c.sims_done = 0; c.sims_started = 0; c.search_active = 0; c.turn_started = 0; c.pending = 0;
             c.arena_state = 1;
         }
@@ -574,6 +608,12 @@ __global__ __launch_bounds__(64) void k_arena_step(Dev E)
                 }
             }
             if (c.slot_games < (uint32_t)ALOG) ws_store(root, E.alog_final + ((size_t)g * ALOG + c.slot_games) * GREC);
+            if (E.arena_collect && c.nsamples) {  // Player::gameFinished -> NNTrainDataStorage::updateValues for both players
+                wave_mem_sync();
+                flush_samples(E, g, c.nsamples, gs, k.ringdrop);
+                k.samples += c.nsamples;
+                c.nsamples = 0;
+            }
             c.slot_games++;
             k.games++;
             c.player_start ^= 1u;  // Game::incPlayerStart
@@ -591,18 +631,34 @@ __global__ __launch_bounds__(64) void k_arena_step(Dev E)
             random_take_turn(root, R);
             fail = root.err != 0 || (root.cur == p && game_status(root, R) == ST_NOT_ENDED);
         } else {
-            if (!c.turn_started) { tree_trim(t, c); c.turn_started = 1; }   // the player's own trimNodes
-            if (!c.search_active) { tree_trim(t, c); c.sims_done = 0; c.sims_started = 0; c.search_active = 1; }  // simulate -> setRootState
+            const uint32_t w = kind == 3 ? 1u : 0u;   // which AlphaZeroPlayer: its tree and its network
+            const Tree& tt = w ? t2 : t;
+            if (w) swap_tree_ctl(c, x2);
+            if (!c.turn_started) { tree_trim(tt, c); c.turn_started = 1; }   // the player's own trimNodes
+            if (!c.search_active) { tree_trim(tt, c); c.sims_done = 0; c.sims_started = 0; c.search_active = 1; }  // simulate -> setRootState
+            c.search_tree = w;
             c.rng = root.rng;
             uint32_t err = 0;
-            int r = search_round(E, g, t, c, root, scratch, k, err);
+            int r = search_round(E, g, tt, c, root, scratch, k, err);
             root.rng = c.rng;
-            if (r == RD_LEAF) break;
+            if (r == RD_LEAF) { if (w) swap_tree_ctl(c, x2); break; }
             if (r == RD_FAIL) { fail = true; root.err = err; }
             else {
                 uint32_t N; uint64_t valid;
                 uint32_t mv = NONE;
-                if (root_node(t, root, N, valid) != NO_NODE) mv = pick_highest(root_policy(N, valid));
+                if (root_node(tt, root, N, valid) != NO_NODE) {
+                    const float pi = root_policy(N, valid);
+                    mv = pick_highest(pi);
+                    if (E.arena_collect) {  // AlphaZeroPlayer::takeTurn with trainStorage set (alphazero_player.cpp:15-18)
+                        if (c.nsamples < (uint32_t)E.SCAP) {
+                            uint8_t* rec = E.stage + ((size_t)g * E.SCAP + c.nsamples) * STAGE_BYTES;
+                            encode88(root, rec);
+                            if (lane_id() < MOVES) reinterpret_cast<float*>(rec + 88)[lane_id()] = pi;
+                            if (lane_id() == 0) rec[260] = (uint8_t)root.cur;
+                            c.nsamples++;
+                        } else k.ringdrop++;
+                    }
+                }
                 if (mv != NONE) make_move(root, mv, R); else root.err = E_LOGIC;
                 c.search_active = 0;
                 c.last_move = mv;
@@ -610,12 +666,22 @@ __global__ __launch_bounds__(64) void k_arena_step(Dev E)
                 fail = root.err != 0;
                 if (root.cur != p || game_status(root, R) != ST_NOT_ENDED) c.turn_started = 0;
             }
+            if (w) swap_tree_ctl(c, x2);
         }
         if (fail) {  // the reference would have thrown out of GameGroup: drop the game, start a fresh pair
             k.err++;
             c.error = root.err ? root.err : (uint32_t)E_LOGIC;
             root.err = 0;
             c.player_start = 0; c.pair_phase = 0; c.arena_state = 0;
+            c.pending = 0; c.search_active = 0; c.turn_started = 0;
+        }
+    }
+    if (two) {
+        if (lane_id() == 0) { uint32_t* d2 = E.tctl2 + (size_t)g * 4; d2[0] = x2.search_id; d2[1] = x2.nfree; d2[2] = x2.hiwater; }
+        // hand every waiting leaf to the network of the player that is searching
+        if (c.pending && lane_id() < (uint32_t)E.T && ((c.pending >> lane_id()) & 1u)) {
+            const int at = atomicAdd(&E.leaf_count[c.search_tree], 1);
+            E.leaf_list[(size_t)c.search_tree * E.G * E.T + at] = g * E.T + (int)lane_id();
         }
     }
     c.rng = root.rng;
@@ -636,6 +702,13 @@ __global__ __launch_bounds__(64) void k_arena_start(Dev E)
     Tree t = tree_of(E, g);
     c.hiwater = (uint32_t)E.C;
     tree_clear(t, c);
+    if (E.nodes2) {  // the opponent player's tree starts empty with its own stamp counter
+        Ctl c2 = c;
+        c2.hiwater = (uint32_t)E.C;
+        tree_clear(tree2_of(E, g), c2);
+        if (lane_id() == 0) { uint32_t* d2 = E.tctl2 + (size_t)g * 4; d2[0] = c2.search_id; d2[1] = c2.nfree; d2[2] = c2.hiwater; d2[3] = 0; }
+    }
+    c.search_tree = 0; c.nsamples = 0;
     c.mode = 3; c.sims_done = 0; c.sims_started = 0; c.pending = 0; c.search_done = 0; c.error = 0;
     c.arena_state = 0; c.player_start = 0; c.pair_phase = 0; c.turn_started = 0; c.search_active = 0; c.slot_games = 0;
     c.seed = E.base_seed + (uint32_t)g;
@@ -841,6 +914,9 @@ extern "C" int azr_engine_destroy(azr_engine* h)
                     d.leaf_valid, d.leaf_hash, d.net_pi, d.net_v, d.stage, d.ring, d.ring_count, d.counters, d.active,
                     d.arena_taken, d.arena_res, d.prev_start, d.script, d.alog_status, d.alog_rounds, d.alog_final};
     for (void* p : ptrs) if (p) hipFree(p);
+    for (void* p : h->tree2) if (p) hipFree(p);
+    if (d.leaf_list) hipFree(d.leaf_list);
+    if (d.leaf_count) hipFree(d.leaf_count);
     train_free(h);
     net_free(h);
     for (hipEvent_t e : h->ev) hipEventDestroy(e);
@@ -1228,16 +1304,22 @@ extern "C" int azr_arena_start(azr_engine* h, int player1, int player2, int game
                                uint32_t base_seed)
 {
     ENTER(h);
-    if (player1 < 0 || player1 > 2 || player2 < 0 || player2 > 2 || games < 0) return AZR_E_INVALID_ARGUMENT;
-    if (player1 == AZR_PLAYER_ALPHAZERO && player2 == AZR_PLAYER_ALPHAZERO) {
-        h->err = "azr_arena_start: AlphaZero vs AlphaZero needs two trees per slot (not built yet)";
+    if (player1 < 0 || player1 > 3 || player2 < 0 || player2 > 3 || games < 0) return AZR_E_INVALID_ARGUMENT;
+    if (player1 == player2 && (player1 == AZR_PLAYER_ALPHAZERO || player1 == AZR_PLAYER_ALPHAZERO_B)) {
+        h->err = "azr_arena_start: two AlphaZero players need one tree each: use AZR_PLAYER_ALPHAZERO vs AZR_PLAYER_ALPHAZERO_B "
+                 "(azr_arena_set_opponent_net(h, h) for the same network on both sides)";
         return AZR_E_STATE;
     }
-    if ((player1 == AZR_PLAYER_ALPHAZERO || player2 == AZR_PLAYER_ALPHAZERO) && !h->weights_set) {
-        h->err = "azr_arena_start: no weights";
+    const bool usesA = player1 == AZR_PLAYER_ALPHAZERO || player2 == AZR_PLAYER_ALPHAZERO;
+    const bool usesB = player1 == AZR_PLAYER_ALPHAZERO_B || player2 == AZR_PLAYER_ALPHAZERO_B;
+    if (usesA && !h->weights_set) { h->err = "azr_arena_start: no weights"; return AZR_E_STATE; }
+    if (usesB && (!h->opponent || !h->opponent->weights_set)) {
+        h->err = "azr_arena_start: AZR_PLAYER_ALPHAZERO_B needs azr_arena_set_opponent_net with a handle that has weights";
         return AZR_E_STATE;
     }
     Dev& d = h->d;
+    d.nodes2 = usesB ? h->tree2[0] ? (uint8_t*)h->tree2[0] : nullptr : nullptr;
+    if (d.arena_collect) HIPCHK(h, hipMemsetAsync(d.ring_count, 0, sizeof(unsigned long long), h->stream));
     d.kind0 = player1; d.kind1 = player2; d.arena_total = games; d.arena_slot_cap = games_per_slot_cap;
     d.arena_mirror = mirror_games; d.base_seed = base_seed;
     h->mode = 3;
@@ -1255,6 +1337,21 @@ extern "C" int azr_arena_run(azr_engine* h, int passes, int* finished_out)
     ENTER(h);
     if (h->mode != 3) { h->err = "azr_arena_run: call azr_arena_start first"; return AZR_E_STATE; }
     const bool needs_net = h->d.kind0 == AZR_PLAYER_ALPHAZERO || h->d.kind1 == AZR_PLAYER_ALPHAZERO;
+    if (h->d.nodes2) {  // two networks: every pass evaluates each net on the leaves of its own player only
+        const int GT = h->d.G * h->d.T;
+        for (int p = 0; p < passes; p++) {
+            HIPCHK(h, hipMemsetAsync(h->d.leaf_count, 0, 2 * sizeof(int), h->stream));
+            LAUNCH(h, k_arena_step, h->d);
+            int cnt[2] = {0, 0};
+            D2H(h, cnt, h->d.leaf_count, sizeof cnt);
+            SYNC(h);
+            if (cnt[0] == 0 && cnt[1] == 0) break;  // every slot is idle: the quota is exhausted
+            int rc = net_forward_ex(h, h->d.leaf_in, LEAF_STRIDE, cnt[0], h->d.net_pi, h->d.net_v, h->d.leaf_list, h->stream);
+            if (rc) return rc;
+            rc = net_forward_ex(h->opponent, h->d.leaf_in, LEAF_STRIDE, cnt[1], h->d.net_pi, h->d.net_v, h->d.leaf_list + GT, h->stream);
+            if (rc) { h->err = h->opponent->err; return rc; }
+        }
+    } else
     for (int p = 0; p < passes; p++) {
         LAUNCH(h, k_arena_step, h->d);
         if (needs_net) {
@@ -1268,6 +1365,44 @@ extern "C" int azr_arena_run(azr_engine* h, int passes, int* finished_out)
     int idle = 0;
     for (uint32_t v : st) idle += v == 2;
     if (finished_out) *finished_out = idle == h->d.G;
+    return AZR_OK;
+}
+
+extern "C" int azr_arena_set_opponent_net(azr_engine* h, azr_engine* other)
+{
+    ENTER(h);
+    if (!other) { h->opponent = nullptr; return AZR_OK; }
+    if (other->cfg.device != h->cfg.device || other->net.blocks != h->net.blocks || other->cfg.net_dtype != h->cfg.net_dtype ||
+        other->d.G * other->d.T < h->d.G * h->d.T) {
+        h->err = "azr_arena_set_opponent_net: the opponent handle must be on the same device with the same net shape and >= leaf slots";
+        return AZR_E_INVALID_ARGUMENT;
+    }
+    Dev& d = h->d;
+    if (!h->tree2[0]) {  // the second AlphaZeroPlayer's tree per slot + the per-net leaf lists
+        const size_t G = d.G, C = d.C;
+        uint8_t* n2 = nullptr; uint32_t *t2 = nullptr, *h2 = nullptr, *tb2 = nullptr, *tc2 = nullptr; uint16_t* f2 = nullptr;
+        HIPCHK(h, dmalloc(&n2, G * C * NODE_BYTES)); h->tree2[0] = n2;
+        HIPCHK(h, dmalloc(&t2, G * C)); h->tree2[1] = t2;
+        HIPCHK(h, dmalloc(&h2, G * C)); h->tree2[2] = h2;
+        HIPCHK(h, dmalloc(&tb2, G * d.H)); h->tree2[3] = tb2;
+        HIPCHK(h, dmalloc(&f2, G * C)); h->tree2[4] = f2;
+        HIPCHK(h, dmalloc(&tc2, G * 4)); h->tree2[5] = tc2;
+        HIPCHK(h, dmalloc(&d.leaf_list, 2 * G * d.T));
+        HIPCHK(h, dmalloc(&d.leaf_count, (size_t)2));
+        HIPCHK(h, hipMemsetAsync(t2, 0, G * C * sizeof(uint32_t), h->stream));
+        HIPCHK(h, hipMemsetAsync(tb2, 0, G * d.H * sizeof(uint32_t), h->stream));
+        HIPCHK(h, hipMemsetAsync(tc2, 0, G * 4 * sizeof(uint32_t), h->stream));
+        d.touch2 = t2; d.nhash2 = h2; d.table2 = tb2; d.freel2 = f2; d.tctl2 = tc2;
+        SYNC(h);
+    }
+    h->opponent = other;
+    return AZR_OK;
+}
+
+extern "C" int azr_arena_collect_samples(azr_engine* h, int on)
+{
+    if (!h) return AZR_E_BAD_HANDLE;
+    h->d.arena_collect = on ? 1 : 0;
     return AZR_OK;
 }
 

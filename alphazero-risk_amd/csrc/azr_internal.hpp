@@ -56,6 +56,17 @@ struct Dev {
     int8_t* alog_status;       // [G][ALOG]
     uint16_t* alog_rounds;     // [G][ALOG]
     uint8_t* alog_final;       // [G][ALOG][64]
+    // two-net arena (trainAZPG vs generateAZPG, alphazero_trainer.cpp:147-152): AZR_PLAYER_ALPHAZERO_B searches its own
+    // tree (every AlphaZeroPlayer owns an AlphaZeroMCTS) and is evaluated by the opponent handle's network
+    uint8_t* nodes2;           // [G][C][NODE_BYTES]   (null until azr_arena_set_opponent_net)
+    uint32_t* touch2;
+    uint32_t* nhash2;
+    uint32_t* table2;
+    uint16_t* freel2;
+    uint32_t* tctl2;           // [G][4]  tree 2's {search_id, nfree, hiwater, -}
+    int* leaf_list;            // [2][G*T] leaf slots waiting for net A / net B after an arena step
+    int* leaf_count;           // [2]
+    int arena_collect;         // stage (s, pi, player) per AlphaZero decision and flush finished games to the record ring
 };
 constexpr int ALOG = 16;
 
@@ -95,6 +106,8 @@ struct azr_engine {
     hipEvent_t pe_tower0 = nullptr, pe_tower1 = nullptr;  // when set, the net records these around its dominant kernel
     int prof_launches;
     bool weights_set;
+    void* tree2[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // nodes2, touch2, nhash2, table2, freel2, tctl2
+    azr_engine* opponent = nullptr;  // handle whose network plays AZR_PLAYER_ALPHAZERO_B (azr_arena_set_opponent_net)
     void* train = nullptr;        // azr_train.hip: optimiser state + activation slabs, created by the first azr_nn_train*
 };
 
@@ -104,6 +117,7 @@ int net_alloc(azr_engine* h);
 void net_free(azr_engine* h);
 int net_upload(azr_engine* h);  // fold BN, pack, copy h->flat to the device
 int net_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v);
+int net_forward_ex(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st);
 size_t net_param_count(int blocks);
 void net_init_random(float* flat, int blocks, uint64_t seed);
 // train (azr_train.hip)

@@ -31,7 +31,7 @@ namespace azr {
 int net_bf16_alloc(azr_engine* h);
 void net_bf16_free(azr_engine* h);
 int net_bf16_upload(azr_engine* h);
-int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v);
+int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st);
 }  // namespace azr
 
 constexpr float BN_EPS = 1e-3f;  // tf.layers.batch_normalization default epsilon
@@ -114,12 +114,12 @@ __device__ __forceinline__ float plane_value(const uint8_t* in88, int pos, int c
 }
 
 __global__ __launch_bounds__(256) void k_stem_f32(const uint8_t* in88, int in_stride, const float* W,
-                                                  const float* scale7, const float* shift7, float* out)
+                                                  const float* scale7, const float* shift7, float* out, const int* slot_map)
 {
     __shared__ float x[FRAME][16];
     __shared__ __attribute__((aligned(16))) uint8_t in[96];
     const int b = blockIdx.x, co = threadIdx.x;
-    if (co < 88) in[co] = in88[(size_t)b * in_stride + co];
+    if (co < 88) in[co] = in88[(size_t)(slot_map ? slot_map[b] : b) * in_stride + co];
     for (int i = co; i < FRAME * 16; i += 256) (&x[0][0])[i] = 0.0f;
     __syncthreads();
     for (int i = co; i < NPOS * NIN; i += 256) {
@@ -196,7 +196,7 @@ template <>
 __device__ __forceinline__ float load_act<uint16_t>(const uint16_t* p) { return __uint_as_float((uint32_t)*p << 16); }
 
 template <typename XT>
-__global__ __launch_bounds__(256) void k_heads(const XT* X, const float* hp, float* pi_out, float* v_out)
+__global__ __launch_bounds__(256) void k_heads(const XT* X, const float* hp, float* pi_out, float* v_out, const int* slot_map)
 {
     __shared__ float feat[128];  // 84 policy features, then 42 value features
     __shared__ float hid[256];
@@ -245,23 +245,24 @@ __global__ __launch_bounds__(256) void k_heads(const XT* X, const float* hp, flo
         float e = t < 43 ? expf(lv - mx) : 0.0f;
         float se = e;
         for (int m = 32; m >= 1; m >>= 1) se += __shfl_xor(se, m);
-        if (t < 43) pi_out[(size_t)b * PI_STRIDE + t] = e / se;
-        if (t == 43) pi_out[(size_t)b * PI_STRIDE + 43] = 0.0f;
+        const int slot = slot_map ? slot_map[b] : b;
+        if (t < 43) pi_out[(size_t)slot * PI_STRIDE + t] = e / se;
+        if (t == 43) pi_out[(size_t)slot * PI_STRIDE + 43] = 0.0f;
     } else if (t < 128) {  // value: sum of 256 products by one wave
         const int l = t - 64;
         float s = hid[l] + hid[l + 64] + hid[l + 128] + hid[l + 192];
         for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-        if (l == 0) v_out[b] = tanhf(s + b2[0]);
+        if (l == 0) v_out[slot_map ? slot_map[b] : b] = tanhf(s + b2[0]);
     }
 }
 
-template __global__ void k_heads<float>(const float*, const float*, float*, float*);
-template __global__ void k_heads<uint16_t>(const uint16_t*, const float*, float*, float*);
+template __global__ void k_heads<float>(const float*, const float*, float*, float*, const int*);
+template __global__ void k_heads<uint16_t>(const uint16_t*, const float*, float*, float*, const int*);
 
 namespace azr {
 void launch_heads_bf16(hipStream_t st, int n, const uint16_t* X, const float* hp, float* pi, float* v)
 {
-    hipLaunchKernelGGL(k_heads<uint16_t>, dim3(n), dim3(256), 0, st, X, hp, pi, v);
+    hipLaunchKernelGGL(k_heads<uint16_t>, dim3(n), dim3(256), 0, st, X, hp, pi, v, (const int*)nullptr);
 }
 }  // namespace azr
 
@@ -347,12 +348,12 @@ const float* net_head_params(azr_engine* h) { return nh(h)->d_flat + off_heads(h
 const float* net_fold(azr_engine* h) { return nh(h)->d_fold; }
 }  // namespace azr
 
-static int net_f32_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v)
+static int net_f32_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st)
 {
     NetDev& N = h->net;
     NetDev* x = nh(h);
-    hipLaunchKernelGGL(k_stem_f32, dim3(n), dim3(256), 0, h->stream, d_in88, in_stride, N.stem_w, N.stem_scale,
-                       N.stem_shift, N.actX);
+    hipLaunchKernelGGL(k_stem_f32, dim3(n), dim3(256), 0, st, d_in88, in_stride, N.stem_w, N.stem_scale,
+                       N.stem_shift, N.actX, d_map);
     const size_t layer = (size_t)9 * NF * NF + 4 * NF;
     const size_t lds = FRAME * NF * sizeof(float);
     for (int b = 0; b < N.blocks; b++) {
@@ -360,23 +361,33 @@ static int net_f32_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, 
         const float* wb = N.tower_w + (size_t)(2 * b + 1) * layer;
         const float* fa = x->d_fold + 14 + (size_t)(2 * b) * 2 * NF;
         const float* fb = x->d_fold + 14 + (size_t)(2 * b + 1) * 2 * NF;
-        hipLaunchKernelGGL(k_conv_f32, dim3(n), dim3(256), lds, h->stream, (const float*)N.actX, wa, fa, fa + NF,
+        hipLaunchKernelGGL(k_conv_f32, dim3(n), dim3(256), lds, st, (const float*)N.actX, wa, fa, fa + NF,
                            (const float*)nullptr, N.actT);
-        hipLaunchKernelGGL(k_conv_f32, dim3(n), dim3(256), lds, h->stream, (const float*)N.actT, wb, fb, fb + NF,
+        hipLaunchKernelGGL(k_conv_f32, dim3(n), dim3(256), lds, st, (const float*)N.actT, wb, fb, fb + NF,
                            (const float*)N.actX, N.actX);
     }
-    hipLaunchKernelGGL(k_heads<float>, dim3(n), dim3(256), 0, h->stream, (const float*)N.actX,
-                       x->d_flat + off_heads(N.blocks), d_pi, d_v);
+    hipLaunchKernelGGL(k_heads<float>, dim3(n), dim3(256), 0, st, (const float*)N.actX,
+                       x->d_flat + off_heads(N.blocks), d_pi, d_v, d_map);
     HIPCHK(h, hipGetLastError());
     return AZR_OK;
 }
 
 int azr::net_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v)
 {
-    if (n <= 0) return AZR_OK;
     if (n > h->d.G * h->d.T) { h->err = "net_forward: batch larger than the engine's leaf slots"; return AZR_E_INVALID_ARGUMENT; }
-    if (h->cfg.net_dtype == AZR_NET_F32) return net_f32_forward(h, d_in88, in_stride, n, d_pi, d_v);
-    return net_bf16_forward(h, d_in88, in_stride, n, d_pi, d_v);
+    return net_forward_ex(h, d_in88, in_stride, n, d_pi, d_v, nullptr, h->stream);
+}
+
+// forward of h's network on caller-supplied buffers and stream; d_map (optional, [n]) = leaf slot of board i, for input
+// and output.  The two-net arena runs the opponent handle's weights on the arena handle's leaves this way.
+int azr::net_forward_ex(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st)
+{
+    if (n <= 0) return AZR_OK;
+    if (h->cfg.net_dtype == AZR_NET_F32) {
+        if (n > h->d.G * h->d.T) { h->err = "net_forward: batch larger than the fp32 activation buffers"; return AZR_E_INVALID_ARGUMENT; }
+        return net_f32_forward(h, d_in88, in_stride, n, d_pi, d_v, d_map, st);
+    }
+    return net_bf16_forward(h, d_in88, in_stride, n, d_pi, d_v, d_map, st);
 }
 
 // ---- C-ABI: AlphaZeroNNId ----------------------------------------------------------------------------

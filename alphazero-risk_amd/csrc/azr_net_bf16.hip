@@ -233,7 +233,7 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
                                            int n, const uint16_t* __restrict__ stem_wp, const uint16_t* __restrict__ tower_wp,
                                            const float* __restrict__ fold, int blocks, const float* __restrict__ hp,
                                            float* __restrict__ pi_out, float* __restrict__ v_out,
-                                           unsigned long long* __restrict__ diag)
+                                           unsigned long long* __restrict__ diag, const int* __restrict__ slot_map)
 {
     using G = Geo<NB>;
     constexpr int ROWS = G::ROWS, MT = G::MT, THREADS = 1024 / NT, WCOLS = NT * 16;
@@ -249,7 +249,9 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
     // ---- stage the NNInputData images, zero the zero rows and the stem feature image
     for (int i = tid; i < NB * 96; i += THREADS) {
         const int b = i / 96, o = i % 96;
-        in_l[i] = (board0 + b < n && o < 88) ? in88[(size_t)(board0 + b) * in_stride + o] : (uint8_t)0;
+        // slot_map (optional): board i of this launch is leaf slot slot_map[i] (two-net arena: each net sees its own leaves)
+        const int slot = (board0 + b < n) ? (slot_map ? slot_map[board0 + b] : board0 + b) : 0;
+        in_l[i] = (board0 + b < n && o < 88) ? in88[(size_t)slot * in_stride + o] : (uint8_t)0;
     }
     for (int i = tid; i < ROWB / 4; i += THREADS) {
         reinterpret_cast<uint32_t*>(bufX + ROWS * ROWB)[i] = 0;
@@ -457,6 +459,7 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
         for (int job = wave; job < NB * 2; job += THREADS / 64) {
             const int bb = job >> 1;
             if (board0 + bb >= n) continue;
+            const int slot = slot_map ? slot_map[board0 + bb] : board0 + bb;
             if ((job & 1) == 0) {
                 const float lv = lane < 43 ? logit[bb * 64 + lane] : -INFINITY;
                 float mx = lv;
@@ -464,13 +467,13 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
                 const float e = lane < 43 ? expf(lv - mx) : 0.0f;
                 float se = e;
                 for (int sft = 32; sft >= 1; sft >>= 1) se += __shfl_xor(se, sft);
-                if (lane < 43) pi_out[(size_t)(board0 + bb) * PI_STRIDE + lane] = e / se;
-                if (lane == 43) pi_out[(size_t)(board0 + bb) * PI_STRIDE + 43] = 0.0f;
+                if (lane < 43) pi_out[(size_t)slot * PI_STRIDE + lane] = e / se;
+                if (lane == 43) pi_out[(size_t)slot * PI_STRIDE + 43] = 0.0f;
             } else {
                 const float* hb = hid + bb * 256;
                 float sacc = hb[lane] + hb[lane + 64] + hb[lane + 128] + hb[lane + 192];
                 for (int sft = 32; sft >= 1; sft >>= 1) sacc += __shfl_xor(sacc, sft);
-                if (lane == 0) v_out[board0 + bb] = tanhf(sacc + b2[0]);
+                if (lane == 0) v_out[slot] = tanhf(sacc + b2[0]);
             }
         }
     }
@@ -486,18 +489,19 @@ __global__ __launch_bounds__(1024 / NT, NT == 2 ? 2 : 1) void k_tower_bf16(const
                                                                            const float* __restrict__ fold, int blocks,
                                                                            const float* __restrict__ hp,
                                                                            float* __restrict__ pi_out, float* __restrict__ v_out,
-                                                                           unsigned long long* __restrict__ diag, int n_full)
+                                                                           unsigned long long* __restrict__ diag, int n_full,
+                                                                           const int* __restrict__ slot_map)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int bid = blockIdx.x;
     if constexpr (NB >= 2) {
         if (bid >= n_full) {
             tower_body<NB - 1, NT>(lds, n_full * NB + (bid - n_full) * (NB - 1), in88, in_stride, n, stem_wp, tower_wp, fold, blocks, hp,
-                                   pi_out, v_out, diag);
+                                   pi_out, v_out, diag, slot_map);
             return;
         }
     }
-    tower_body<NB, NT>(lds, bid * NB, in88, in_stride, n, stem_wp, tower_wp, fold, blocks, hp, pi_out, v_out, diag);
+    tower_body<NB, NT>(lds, bid * NB, in88, in_stride, n, stem_wp, tower_wp, fold, blocks, hp, pi_out, v_out, diag, slot_map);
 }
 
 struct Bf16Net {
@@ -575,19 +579,19 @@ int net_bf16_upload(azr_engine* h)
     return AZR_OK;
 }
 
-int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v)
+int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st)
 {
     Bf16Net* x = bn(h);
     const float* fold = net_fold(h);
     const int B = h->net.blocks;
-    if (h->pe_tower0) hipEventRecord(h->pe_tower0, h->stream);
+    if (h->pe_tower0) hipEventRecord(h->pe_tower0, st);
     // boards per workgroup: fill the 256 CUs first, then grow the M tile.  Wave tiling: 8 waves x 32 channels by
     // default; AZR_TOWER_NT=4 selects the 4-wave x 64-channel shape (measured equal at NB = 1, 2; slower at NB = 3).
     static const int nt_env = getenv("AZR_TOWER_NT") ? atoi(getenv("AZR_TOWER_NT")) : 0;
     const int NT = nt_env == 4 ? 4 : 2;
 #define LAUNCH_TOWER(NBV, NTV)                                                                                      \
     hipLaunchKernelGGL((k_tower_bf16<NBV, NTV>), dim3(wgs), dim3(1024 / NTV), Geo<NBV>::LDS_BYTES,                 \
-                       h->stream, d_in88, in_stride, n, x->stem_wp, x->tower_wp, fold, B, net_head_params(h), d_pi, d_v, x->diag, n_full)
+                       st, d_in88, in_stride, n, x->stem_wp, x->tower_wp, fold, B, net_head_params(h), d_pi, d_v, x->diag, n_full, d_map)
     // One workgroup per CU is resident (LDS and VGPR budget), so the batch is cut into r rounds of 256 workgroups and
     // the boards are dealt as evenly as 1..3 per workgroup allows: `n_full` workgroups of nb boards first, the rest nb - 1.
     const int rounds = (n + 767) / 768, W = 256 * rounds;
@@ -600,7 +604,7 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
     else if (nb == 2) { if (NT == 2) LAUNCH_TOWER(2, 2); else LAUNCH_TOWER(2, 4); }
     else { if (NT == 2) LAUNCH_TOWER(3, 2); else LAUNCH_TOWER(3, 4); }
 #undef LAUNCH_TOWER
-    if (h->pe_tower1) hipEventRecord(h->pe_tower1, h->stream);
+    if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
     HIPCHK(h, hipGetLastError());
     return AZR_OK;
 }
@@ -616,9 +620,9 @@ extern "C" int azr_debug_tower_clock(azr_engine* h, int n, int warm, double* ghz
     Bf16Net* x = bn(h);
     unsigned long long* d = nullptr;
     HIPCHK(h, hipMalloc((void**)&d, 4 * sizeof(unsigned long long)));
-    for (int i = 0; i < warm; i++) net_bf16_forward(h, h->d.leaf_in, LEAF_STRIDE, n, h->d.net_pi, h->d.net_v);
+    for (int i = 0; i < warm; i++) net_bf16_forward(h, h->d.leaf_in, LEAF_STRIDE, n, h->d.net_pi, h->d.net_v, nullptr, h->stream);
     x->diag = d;
-    int rc = net_bf16_forward(h, h->d.leaf_in, LEAF_STRIDE, n, h->d.net_pi, h->d.net_v);
+    int rc = net_bf16_forward(h, h->d.leaf_in, LEAF_STRIDE, n, h->d.net_pi, h->d.net_v, nullptr, h->stream);
     x->diag = nullptr;
     unsigned long long v[4] = {0, 0, 0, 0};
     HIPCHK(h, hipMemcpyAsync(v, d, sizeof v, hipMemcpyDeviceToHost, h->stream));

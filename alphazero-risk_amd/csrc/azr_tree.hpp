@@ -61,7 +61,7 @@ struct alignas(128) Ctl {
     uint32_t slot_games;   // games finished in this slot
     uint32_t dup_dropped;  // StateSimulationsStorage::duplicatedStatesDropped
     uint32_t plen[MAX_THREADS];  // path length of thread k's pending descent (0 = setRootState's root expansion)
-    uint32_t pad[1];
+    uint32_t search_tree;  // two-net arena: tree (= net) of the search in flight, 0 = this handle's, 1 = the opponent's
 };
 static_assert(sizeof(Ctl) == 128, "Ctl must be one line");
 

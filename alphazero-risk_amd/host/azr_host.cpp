@@ -544,92 +544,56 @@ std::ostream& operator<<(std::ostream& os, const GameResults& gr)  // game.cpp:2
               << gr.players[1].winAndStartedGame;
 }
 
-// State::invertPlayers (state.cpp:493-516) on the byte image: swap owners 0 <-> 1 and the two PlayerStatus blocks
-static void invertPlayers(State& s)
-{
-    for (int i = 0; i < 42; i++) {
-        const uint8_t la = s.data[i], owner = la >> 6;
-        if (owner < 2) s.data[i] = (uint8_t)((la & 63) | ((owner ^ 1) << 6));
-    }
-    uint8_t tmp[48];
-    memcpy(tmp, s.data + 48, 48);
-    memcpy(s.data + 48, s.data + 96, 48);
-    memcpy(s.data + 96, tmp, 48);
-}
-
 GameResults GameGroup::playGames(AlphaZeroPlayerGroup& pg1, AlphaZeroPlayerGroup& pg2, int games, NNTrainDataStorage* tds)
 {
+    // Device-resident arena: pg1's engine of GPU i runs the G slots, pg2's network of the same GPU plays
+    // AZR_PLAYER_ALPHAZERO_B (own tree per slot, evaluated on its own leaves).  Every slot is one of the reference's
+    // threadPlayGame threads taking mirrored pairs from the shared counter (game.cpp:238-254).
     const int P = (int)pg1.nnGroup->size();
     printf("Playing games %d\n", games);
-    std::vector<GameResults> res(P);
-    const int G = pg1.nnGroup->getNN(0)->engine->games;
-    std::vector<std::vector<NNTrainDataStorage>> st1(P, std::vector<NNTrainDataStorage>(tds ? G : 0)), st2 = st1;
+    std::vector<azr_game_results> res(P);
+    std::vector<NNTrainDataStorage> st(P);
     std::vector<std::thread> threads;
-    const int pairs = games / 2;  // Counter::hasNext(2) (game.cpp:241-253): whole pairs only
+    const int pairs = games / 2;  // Counter::hasNext(2): whole pairs only
     for (int i = 0; i < P; i++)
         threads.emplace_back([&, i]() {
-            Engine& e1 = *pg1.nnGroup->getNN(i)->engine;
-            AlphaZeroMCTS m1(pg1.nnGroup->getNN(i)), m2(pg2.nnGroup->getNN(i));
-            int quota = pairs / P + (i < pairs % P ? 1 : 0);  // pairs for this GPU
-            uint32_t seed = SETTINGS.BASE_SEED + 7919u + (uint32_t)i * (1u << 24);
-            std::vector<uint8_t> img((size_t)G * AZR_STATE_BYTES);
-            std::vector<int8_t> status(G);
-            while (quota > 0) {
-                const int take = std::min(G, quota);  // slot k < take plays pair k; the other slots' games are not counted
-                quota -= take;
-                std::vector<uint32_t> seeds(G);
-                for (int g = 0; g < G; g++) seeds[g] = seed++;
-                e1.check(azr_engine_new_games(e1.h, seeds.data()), "new_games");
-                e1.check(azr_engine_get_states(e1.h, img.data()), "get_states");
-                std::vector<State> start(G);
-                for (int g = 0; g < G; g++) memcpy(start[g].data, img.data() + (size_t)g * AZR_STATE_BYTES, AZR_STATE_BYTES);
-                for (int playerStart = 0; playerStart < 2; playerStart++) {  // Game::newGame + incPlayerStart
-                    std::vector<State> states = start;
-                    if (playerStart == 1) {
-                        if (SETTINGS.MIRROR_GAMES) for (auto& s : states) invertPlayers(s);
-                        else {
-                            for (int g = 0; g < G; g++) seeds[g] = seed++;
-                            e1.check(azr_engine_new_games(e1.h, seeds.data()), "new_games");
-                            e1.check(azr_engine_get_states(e1.h, img.data()), "get_states");
-                            for (int g = 0; g < G; g++) memcpy(states[g].data, img.data() + (size_t)g * AZR_STATE_BYTES, AZR_STATE_BYTES);
-                        }
-                    }
-                    for (auto& s : states) s.data[146] = (uint8_t)playerStart;  // setCurrentPlayerTurn
-                    m1.clearNodes();  // AlphaZeroPlayer::newGame
-                    m2.clearNodes();
-                    for (;;) {        // Game::gameLoop
-                        pg1.takeTurns(i, states, 0, tds ? &st1[i] : nullptr);
-                        pg2.takeTurns(i, states, 1, tds ? &st2[i] : nullptr);
-                        for (int g = 0; g < G; g++) memcpy(img.data() + (size_t)g * AZR_STATE_BYTES, states[g].data, AZR_STATE_BYTES);
-                        e1.check(azr_engine_set_states(e1.h, img.data()), "set_states");
-                        e1.check(azr_engine_status(e1.h, status.data()), "status");
-                        bool running = false;
-                        for (int g = 0; g < G; g++) running |= status[g] == -1;
-                        if (!running) break;
-                    }
-                    for (int g = 0; g < G; g++) {
-                        if (tds) {  // gameFinished -> updateValues; uncounted slots drop their records
-                            if (g < take) { st1[i][g].updateValues(status[g], states[g].getRound()); st2[i][g].updateValues(status[g], states[g].getRound()); }
-                            else { st1[i][g].data.resize(st1[i][g].lastGameIndex); st2[i][g].data.resize(st2[i][g].lastGameIndex); }
-                        }
-                        if (g < take) res[i].addGame(status[g], playerStart);
-                    }
-                    if (i == 0) {
-                        printf("\r%d [Draw/P1,P2]: %d, %d/%d, %d/%d", res[i].count, res[i].draw, res[i].players[0].win,
-                               res[i].players[0].winAndStartedGame, res[i].players[1].win, res[i].players[1].winAndStartedGame);
-                        fflush(stdout);
-                    }
+            Engine& e = *pg1.nnGroup->getNN(i)->engine;
+            Engine& o = *pg2.nnGroup->getNN(i)->engine;
+            memset(&res[i], 0, sizeof res[i]);
+            const int share = 2 * (pairs / P + (i < pairs % P ? 1 : 0));
+            if (share == 0) return;
+            e.check(azr_arena_set_opponent_net(e.h, o.h), "arena_set_opponent_net");
+            e.check(azr_arena_collect_samples(e.h, tds ? 1 : 0), "arena_collect_samples");
+            e.check(azr_arena_start(e.h, AZR_PLAYER_ALPHAZERO, AZR_PLAYER_ALPHAZERO_B, share, 0, SETTINGS.MIRROR_GAMES,
+                                    SETTINGS.BASE_SEED + 7919u + (uint32_t)i * (1u << 24)), "arena_start");
+            int fin = 0;
+            std::vector<uint8_t> buf;
+            while (!fin) {
+                e.check(azr_arena_run(e.h, 4 * (SETTINGS.MCTS_SIMULATIONS + 2), &fin), "arena_run");
+                e.check(azr_arena_results(e.h, &res[i]), "arena_results");
+                if (tds) {
+                    size_t n = 0;
+                    buf.resize((size_t)e.games * 4096 * AZR_RECORD_BYTES / 8);
+                    e.check(azr_samples_drain(e.h, buf.data(), buf.size() / AZR_RECORD_BYTES, &n), "drain");
+                    st[i].appendPacked(buf.data(), n);
+                }
+                if (i == 0) {
+                    printf("\r%d/%d [Draw/P1,P2]: %d, %d/%d, %d/%d", res[i].count, share, res[i].draw, res[i].win[0], res[i].win_and_started[0],
+                           res[i].win[1], res[i].win_and_started[1]);
+                    fflush(stdout);
                 }
             }
+            e.check(azr_arena_collect_samples(e.h, 0), "arena_collect_samples");
+            e.check(azr_arena_set_opponent_net(e.h, nullptr), "arena_set_opponent_net");
         });
     for (auto& t : threads) t.join();
     printf("\n");
     GameResults all;
-    for (auto& r : res) all.add(r);
-    if (tds) {
-        for (auto& per : st1) for (auto& s : per) tds->extend(s);
-        for (auto& per : st2) for (auto& s : per) tds->extend(s);
+    for (auto& r : res) {
+        all.count += r.count; all.draw += r.draw;
+        for (int p = 0; p < 2; p++) { all.players[p].win += r.win[p]; all.players[p].winAndStartedGame += r.win_and_started[p]; }
     }
+    if (tds) for (auto& s : st) tds->extend(s);
     return all;
 }
 

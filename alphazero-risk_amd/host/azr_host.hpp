@@ -223,10 +223,11 @@ struct GameResults {
 };
 std::ostream& operator<<(std::ostream& os, const GameResults& gr);
 
-// GameGroup::playGames (game.cpp:256-312).  AlphaZero vs AlphaZero (two nets = two engines per GPU) runs the G slots
-// of a GPU as G lock-stepped Game objects — mirrored pairs, alternating starts (game.cpp:153-191) — one host thread per
-// GPU; AlphaZero vs Script/Random runs on the device arena (azr_arena_*).  `tds` (optional) collects the (s, pi, z)
-// records both AlphaZero players push during the games (alphazero_player.cpp:15-18,24-29), storages in player order.
+// GameGroup::playGames (game.cpp:256-312) on the device arena (azr_arena_*), one host thread per GPU.  AlphaZero vs
+// AlphaZero (two nets = two engines per GPU): pg2's network plays AZR_PLAYER_ALPHAZERO_B inside pg1's engine, every slot
+// a pair of AlphaZeroPlayers with their own trees playing mirrored pairs with alternating starts (game.cpp:153-191).
+// `tds` (optional) collects the (s, pi, z) records both AlphaZero players push during the games
+// (alphazero_player.cpp:15-18,24-29), game by game.
 class GameGroup {
 public:
     static GameResults playGames(AlphaZeroPlayerGroup& pg1, AlphaZeroPlayerGroup& pg2, int games, NNTrainDataStorage* tds = nullptr);

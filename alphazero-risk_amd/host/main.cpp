@@ -20,8 +20,8 @@ static void executeTrain()
 }
 
 // `-m play` (src/alphazero_risk.cpp:4-47): GameGroup::playGames(group1, group2, COMPARE_GAMES) on the device arena.
-// az vs sp / rp (either side) and sp / rp among themselves run through azr_arena_*; az vs az goes through the batched
-// Player seam (AlphaZeroPlayerGroup::takeTurns) with one shared net.
+// Every pairing runs through azr_arena_*; az vs az = two AlphaZeroPlayers with their own trees and checkpoints
+// (AZR_PLAYER_ALPHAZERO vs AZR_PLAYER_ALPHAZERO_B).
 static int playerKind(const std::string& p)
 {
     if (p == "az") return AZR_PLAYER_ALPHAZERO;
@@ -30,38 +30,11 @@ static int playerKind(const std::string& p)
     throw std::invalid_argument("unknown player '" + p + "' (az/sp/rp)");
 }
 
-static void executePlayAzVsAz(std::shared_ptr<AlphaZeroNNGroup> group)
+static void executePlayAzVsAz(std::shared_ptr<AlphaZeroNNGroup> group1, std::shared_ptr<AlphaZeroNNGroup> group2)
 {
-    AlphaZeroPlayerGroup players(group);
-    Engine& e = *group->getNN(0)->engine;
-    const int G = e.games;
-    int wins[2] = {0, 0}, draws = 0, count = 0;
-    uint32_t next_seed = SETTINGS.BASE_SEED;
-    while (count < SETTINGS.COMPARE_GAMES) {
-        std::vector<uint32_t> seeds(G);
-        for (int g = 0; g < G; g++) seeds[g] = next_seed++;
-        e.check(azr_engine_new_games(e.h, seeds.data()), "new_games");
-        std::vector<uint8_t> img((size_t)G * AZR_STATE_BYTES);
-        e.check(azr_engine_get_states(e.h, img.data()), "get_states");
-        std::vector<State> states(G);
-        for (int g = 0; g < G; g++) memcpy(states[g].data, img.data() + (size_t)g * AZR_STATE_BYTES, AZR_STATE_BYTES);
-        std::vector<int8_t> status(G, -1);
-        for (;;) {
-            players.takeTurns(0, states, 0);
-            players.takeTurns(0, states, 1);
-            e.check(azr_engine_status(e.h, status.data()), "status");
-            bool running = false;
-            for (int g = 0; g < G; g++) running |= status[g] == -1;
-            if (!running) break;
-        }
-        for (int g = 0; g < G && count < SETTINGS.COMPARE_GAMES; g++, count++) {
-            if (status[g] == State::DRAW) draws++;
-            else wins[status[g]]++;
-        }
-        printf("\rGames: %d", count);
-        fflush(stdout);
-    }
-    printf("\nGames: %d\nDraws:%d\nPlayer 1:%d\nPlayer 2:%d\n", count, draws, wins[0], wins[1]);
+    AlphaZeroPlayerGroup p1(group1), p2(group2);
+    GameResults gr = GameGroup::playGames(p1, p2, SETTINGS.COMPARE_GAMES);
+    printf("Games: %d\nDraws:%d\nPlayer 1:%d\nPlayer 2:%d\n", gr.count, gr.draw, gr.players[0].win, gr.players[1].win);
 }
 
 static void executePlay()
@@ -72,7 +45,12 @@ static void executePlay()
     auto group = cluster->initPlayerGroup("az1", SETTINGS.GRAPH_DEF_PB_1);
     if (k1 == AZR_PLAYER_ALPHAZERO) group->loadCheckpoint(SETTINGS.CHECKPOINT_1);
     else if (k2 == AZR_PLAYER_ALPHAZERO) group->loadCheckpoint(SETTINGS.CHECKPOINT_2);
-    if (k1 == AZR_PLAYER_ALPHAZERO && k2 == AZR_PLAYER_ALPHAZERO) { executePlayAzVsAz(group); return; }
+    if (k1 == AZR_PLAYER_ALPHAZERO && k2 == AZR_PLAYER_ALPHAZERO) {  // two AlphaZeroPlayers, each with its checkpoint
+        auto group2 = cluster->initPlayerGroup("az2", SETTINGS.GRAPH_DEF_PB_2);
+        group2->loadCheckpoint(SETTINGS.CHECKPOINT_2);
+        executePlayAzVsAz(group, group2);
+        return;
+    }
     // one host thread per GPU, the game quota split over the GPUs (the reference shares one Counter)
     const int P = (int)group->size();
     std::vector<azr_game_results> res(P);

@@ -102,6 +102,22 @@ def arena_two_nets(eng_new, eng_old, games, mirror=True, base_seed=1):
                         res["win_and_started"][status[g]] += 1
 
 
+def arena_device(eng_new, eng_old, games, mirror=True, base_seed=1, collect=False):
+    """the same arena resident on the device (azr_arena_* with AZR_PLAYER_ALPHAZERO_B = eng_old's network): every slot
+    advances on its own, each network is evaluated on its own player's leaves; optionally returns the (s, pi, z)
+    records both players produced (INCLUDE_COMPARE_GAMES_TRAIN_SAMPLES)"""
+    eng_new.arena_set_opponent(eng_old)
+    eng_new.arena_collect_samples(collect)
+    eng_new.arena_start(P.PLAYER_ALPHAZERO, P.PLAYER_ALPHAZERO_B, games, 0, mirror, base_seed)
+    while not eng_new.arena_run(4 * (eng_new.settings.mcts_simulations + 2)):
+        pass
+    gr = eng_new.arena_results()
+    recs = eng_new.drain() if collect else np.zeros((0, 265), np.uint8)
+    eng_new.arena_collect_samples(False)
+    eng_new.arena_set_opponent(None)
+    return gr, recs
+
+
 def is_model_improved(gr, threshold):
     """AlphaZeroTrainer::isModelImproved (alphazero_trainer.cpp:192-198): `int >= int * float` evaluated in fp32"""
     return bool(np.float32(gr["win"][0]) >= np.float32(gr["win"][0] + gr["win"][1]) * np.float32(threshold))
@@ -142,6 +158,9 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
     os.makedirs("checkpoints", exist_ok=True)
     dtype = P.NET_BF16 if a.dtype == "bf16" else P.NET_F32
     t = getattr(a, "t", 2)
+    if getattr(a, "trainer", "native") == "torch":
+        import torch   # torch bundles its own HIP runtime: it has to initialise the device before the C-ABI library does
+        torch.cuda.init()
     if rank != 0:
         log = lambda *_: None   # noqa: E731  (rank 0 reports)
     gen = P.Engine(a.gpu_games, blocks=a.blocks, sims=a.mcts, dtype=dtype, device=a.device, threads=t)
@@ -212,18 +231,30 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
         # ---- updateIfImprovement (alphazero_trainer.cpp:134-190)
         improved = True
         gr = None
+        t_arena = time.time()
         if a.cg > 0:
-            gr = arena_two_nets(new, gen, 2 * shard_mod.split_count(a.cg // 2, world, rank), True,
-                                shard_mod.rank_base_seed(a.seed + 7919 * (it + 1), rank))
+            share = 2 * shard_mod.split_count(a.cg // 2, world, rank)
+            aseed = shard_mod.rank_base_seed(a.seed + 7919 * (it + 1), rank)
+            if getattr(a, "arena", "device") == "host":
+                gr, arecs = arena_two_nets(new, gen, share, True, aseed), np.zeros((0, 265), np.uint8)
+            else:
+                gr, arecs = arena_device(new, gen, share, True, aseed, collect=bool(getattr(a, "include_compare_samples", 1)))
             if dist is not None:
                 gr = reduce_results(gr, dist, cdev)
+                import torch
+                arecs = shard_mod.gather_records(torch.from_numpy(arecs).to(cdev), dist).cpu().numpy()
+            if len(arecs):   # playGames(..., trainStorage): the compare games' samples join the replay buffer
+                records = np.concatenate([records, arecs])
+                log(f"New samples generated from compare games {len(arecs)}")
             imp_log.write(f"{it},{gr_str(gr)}\n"); imp_log.flush()
             improved = is_model_improved(gr, a.ct)
+            log(f"Compare games: {gr_str(gr)}   [{gr['count']} games in {time.time() - t_arena:.1f} s]")
         if improved:
             log("Model improved")
             if rank == 0:
                 new.save(best); new.save(f"checkpoints/checkpoint-iter-{it}.bin")
             gen.set_weights(new.get_weights())   # generateGroup->loadCheckpoint(best): every rank already holds them
+            t_bench = time.time()
             r = run_arena(gen, P.PLAYER_ALPHAZERO, P.PLAYER_RANDOM, 2 * shard_mod.split_count(5, world, rank), True,
                           shard_mod.rank_base_seed(a.seed + 11, rank))
             s = run_arena(gen, P.PLAYER_ALPHAZERO, P.PLAYER_SCRIPT, 2 * shard_mod.split_count(50, world, rank), True,
@@ -231,7 +262,7 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
             if dist is not None:
                 r, s = reduce_results(r, dist, cdev), reduce_results(s, dist, cdev)
             bench_log.write(f"{it},{gr_str(r)}, {gr_str(s)}\n"); bench_log.flush()
-            log(f"Model benchmark: vs Random {r['win'][0]}/{r['count']}, vs Script {s['win'][0]}/{s['count']}")
+            log(f"Model benchmark: vs Random {r['win'][0]}/{r['count']}, vs Script {s['win'][0]}/{s['count']}   [{time.time() - t_bench:.1f} s]")
             old_game_index = max(len(records) - 1, 0)   # updateOldGamesIndex
         else:
             log("Model did not improve\nModel reverted back old")
@@ -266,6 +297,9 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--trainer", default="native", choices=["native", "torch"])
+    ap.add_argument("--arena", default="device", choices=["device", "host"],
+                    help="new-vs-old compare games resident on the device (default) or stepped from the host through the Player seam")
+    ap.add_argument("--include-compare-samples", type=int, default=1)   # INCLUDE_COMPARE_GAMES_TRAIN_SAMPLES
     a = ap.parse_args()
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1:

@@ -168,7 +168,8 @@ int azr_samples_device_view(azr_engine* h, void** dev_ptr_out, size_t* n_out);
  * mirrored pairs with alternating starts (Game::newGame, game.cpp:170-191) — until Counter::hasNext(2) fails.
  * Players: AlphaZeroPlayer (alphazero_player.cpp:3-21, argmax, tree trimmed at every turn), ScriptPlayer
  * (player/script/script_player.cpp), RandomPlayer (player/random/random_player.cpp). */
-enum { AZR_PLAYER_ALPHAZERO = 0, AZR_PLAYER_SCRIPT = 1, AZR_PLAYER_RANDOM = 2 };
+enum { AZR_PLAYER_ALPHAZERO = 0, AZR_PLAYER_SCRIPT = 1, AZR_PLAYER_RANDOM = 2,
+       AZR_PLAYER_ALPHAZERO_B = 3 /* AlphaZeroPlayer on a second network: azr_arena_set_opponent_net */ };
 typedef struct azr_game_results {   /* GameResults (game/game.h:17-29) */
     int32_t count, draw;
     int32_t win[2], win_and_started[2];
@@ -177,6 +178,16 @@ typedef struct azr_game_results {   /* GameResults (game/game.h:17-29) */
 int azr_arena_start(azr_engine* h, int player1, int player2, int games, int games_per_slot_cap, int mirror_games,
                     uint32_t base_seed);
 int azr_arena_run(azr_engine* h, int passes, int* finished_out);
+/* New-vs-old arena (GameGroup::playGames(trainAZPG, generateAZPG, ...), alphazero_trainer.cpp:147-152): player
+ * AZR_PLAYER_ALPHAZERO_B searches a tree of its own in every slot (every AlphaZeroPlayer owns an AlphaZeroMCTS) and is
+ * evaluated by `other`'s network (same device, same net shape; `other` may be h itself; its weights are used in place,
+ * so keep `other` alive and pass NULL here before destroying it).  Each pass runs the two networks on the leaves of
+ * their own players only. */
+int azr_arena_set_opponent_net(azr_engine* h, azr_engine* other);
+/* INCLUDE_COMPARE_GAMES_TRAIN_SAMPLES (alphazero_trainer.cpp:143-146): AlphaZero players push (s, pi) at every decision
+ * (alphazero_player.cpp:15-18); a finished game's records get their z and go to the record ring (azr_samples_drain),
+ * game by game in decision order (the reference appends player by player).  Set before azr_arena_start. */
+int azr_arena_collect_samples(azr_engine* h, int on);
 int azr_arena_results(azr_engine* h, azr_game_results* out);
 /* per slot: games finished, and for its first 16 games status / round count / final state image */
 int azr_arena_log(azr_engine* h, int32_t* games_per_slot_host, int8_t* status_host /*[G][16]*/,

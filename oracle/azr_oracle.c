@@ -1851,7 +1851,11 @@ int orc_random_take_turn(orc_state* s, int me, orc_rng* r, const orc_settings* c
 }
 
 /* AlphaZeroPlayer::takeTurn (alphazero_player.cpp:3-21) at one search thread */
-static int az_take_turn(orc_mcts* m, orc_state* s, int me, orc_rng* r, const orc_settings* cfg, orc_eval_fn eval, void* ctx)
+/* optional (s, pi, player) log of the AlphaZero decisions of the running game (alphazero_player.cpp:15-18) */
+typedef struct { uint8_t* rec; int cap, n, game_start; } orc_reclog;
+
+static int az_take_turn(orc_mcts* m, orc_state* s, int me, orc_rng* r, const orc_settings* cfg, orc_eval_fn eval, void* ctx,
+                        orc_reclog* log)
 {
     orc_mcts_trim(m);
     while (orc_game_status(s, cfg) == ORC_NOT_ENDED && s->cur == me) {
@@ -1859,6 +1863,14 @@ static int az_take_turn(orc_mcts* m, orc_state* s, int me, orc_rng* r, const orc
         float pi[ORC_MOVES];
         TRY(orc_mcts_policy(m, s, pi));
         int li = orc_pick_highest(pi);
+        if (log && log->rec && log->n < log->cap) {
+            uint8_t* d = log->rec + (size_t)log->n * 265;
+            d[0] = (uint8_t)s->cur;
+            orc_encode(s, d + 1);
+            memset(d + 89, 0, 4);
+            memcpy(d + 93, pi, 43 * 4);
+            log->n++;
+        }
         TRY(orc_make_move(s, li, r, cfg));
     }
     return ORC_OK;
@@ -1871,6 +1883,18 @@ int orc_play_games(const orc_settings* cfg, int kind0, int kind1, int games, int
                    orc_eval_fn eval, void* ctx, orc_results* res, int8_t* status_out, uint8_t* finals160,
                    uint16_t* rounds_out)
 {
+    return orc_play_games2(cfg, kind0, kind1, games, mirror, seed, eval, ctx, eval, ctx, res, status_out, finals160, rounds_out,
+                           NULL, 0, NULL, NULL);
+}
+
+/* the same with kind 3 = an AlphaZero player on a second network (eval_b) — GameGroup::playGames(trainAZPG,
+ * generateAZPG, ...) of the trainer — and optionally the 265-byte (s, pi, z) records of the AlphaZero decisions, game
+ * by game in decision order, z filled in when the game ends (NNTrainDataStorage::updateValues) */
+int orc_play_games2(const orc_settings* cfg, int kind0, int kind1, int games, int mirror, uint32_t seed,
+                    orc_eval_fn eval, void* ctx, orc_eval_fn eval_b, void* ctx_b, orc_results* res, int8_t* status_out,
+                    uint8_t* finals160, uint16_t* rounds_out, uint8_t* rec265, int rec_cap, int* rec_n, int* rec_game_end)
+{
+    orc_reclog log = {rec265, rec_cap, 0, 0};
     orc_rng r;
     orc_rng_seed(&r, seed);
     orc_script sp[2];
@@ -1878,7 +1902,7 @@ int orc_play_games(const orc_settings* cfg, int kind0, int kind1, int games, int
     const int kind[2] = {kind0, kind1};
     for (int p = 0; p < 2; p++) {
         orc_script_init(&sp[p]);
-        if (kind[p] == 0) mc[p] = orc_mcts_create(cfg);
+        if (kind[p] == 0 || kind[p] == 3) mc[p] = orc_mcts_create(cfg);
     }
     memset(res, 0, sizeof *res);
     orc_state s, prev_start;
@@ -1902,12 +1926,19 @@ int orc_play_games(const orc_settings* cfg, int kind0, int kind1, int games, int
             int setup = s.phase == ORC_SETUP;
             if (kind[cur] == 1) rc = orc_script_take_turn(&sp[cur], &s, &r, cfg);
             else if (kind[cur] == 2) rc = orc_random_take_turn(&s, cur, &r, cfg);
-            else rc = az_take_turn(mc[cur], &s, cur, &r, cfg, eval, ctx);
+            else if (kind[cur] == 3) rc = az_take_turn(mc[cur], &s, cur, &r, cfg, eval_b, ctx_b, &log);
+            else rc = az_take_turn(mc[cur], &s, cur, &r, cfg, eval, ctx, &log);
             if (rc) break;
             gs = setup ? ORC_NOT_ENDED : orc_game_status(&s, cfg);
             if (cur == s.cur && gs == ORC_NOT_ENDED) { rc = ORC_LOGIC_ERROR; break; } /* "Turn was not incremented" */
         }
         if (rc) break;
+        for (int i = log.game_start; i < log.n; i++) { /* updateValues (alphazero_nn_data.cpp:51-65) */
+            float z = gs == ORC_DRAW ? 0.0f : ((int)log.rec[(size_t)i * 265] == gs ? 1.0f : -1.0f);
+            memcpy(log.rec + (size_t)i * 265 + 89, &z, 4);
+        }
+        log.game_start = log.n;
+        if (rec_game_end) rec_game_end[gi] = log.n;
         res->count++;
         if (gs == ORC_DRAW) res->draw++;
         for (int p = 0; p < 2; p++)
@@ -1920,5 +1951,6 @@ int orc_play_games(const orc_settings* cfg, int kind0, int kind1, int games, int
     for (int p = 0; p < 2; p++)
         if (mc[p]) orc_mcts_destroy(mc[p]);
     res->rng_state = r.x;
+    if (rec_n) *rec_n = log.n;
     return rc;
 }

@@ -274,6 +274,22 @@ def orc_play_games(kind0, kind1, games, mirror, seed, cfg=None, eval_fn=None):
     return res.as_tuple(), st, rd, fin, res.rng_state
 
 
+def orc_play_games2(kind0, kind1, games, mirror, seed, cfg, eval_a, eval_b, rec_cap=8192):
+    """the same with kind 3 = AlphaZero on a second network (eval_b) and the (s, pi, z) records of the AlphaZero decisions"""
+    L = oracle()
+    res = OrcResults()
+    st = np.zeros(games, np.int8)
+    fin = np.zeros((games, 160), np.uint8)
+    rd = np.zeros(games, np.uint16)
+    rec = np.zeros((rec_cap, 265), np.uint8)
+    n = C.c_int(0)
+    ends = np.zeros(games, np.int32)
+    rc = L.orc_play_games2(C.byref(cfg), kind0, kind1, games, int(mirror), seed, eval_a, None, eval_b, None, C.byref(res),
+                           ptr(st), ptr(fin), ptr(rd), ptr(rec), rec_cap, C.byref(n), ptr(ends))
+    assert rc == 0, rc
+    return res.as_tuple(), st, rd, fin, [rec[a:b].copy() for a, b in zip([0] + list(ends[:-1]), ends)]
+
+
 def ref_play_games(kind0, kind1, games, mirror, seed):
     L = ref()
     r6 = (C.c_int * 6)()

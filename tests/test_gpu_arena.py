@@ -83,3 +83,55 @@ def test_alphazero_vs_script_config0_bit_exact(orc, az_first):
         tot += np.array(r6)
     assert res["count"] == tot[0] and res["win"][0] == tot[2] and res["win"][1] == tot[4]
     eng.close()
+
+
+@pytest.mark.parametrize("threads,b_first", [(1, False), (2, False), (2, True)])
+def test_two_net_arena_bit_exact_with_samples(orc, threads, b_first):
+    """New-vs-old arena of the learn loop (GameGroup::playGames(trainAZPG, generateAZPG, ..., trainStorage),
+    alphazero_trainer.cpp:143-152): two AlphaZero players with their own trees and DIFFERENT networks in every slot, each
+    network evaluated on its own player's leaves only, (s, pi, z) records collected from both players.  Oracle side: the
+    same game driver with the two DEVICE nets called back per evaluation."""
+    P = pkg()
+    G, per_slot, S, B, base = 6, 2, 12, 1, 5200
+    a = P.Engine(G, blocks=B, sims=S, dtype=P.NET_BF16, threads=threads, max_game_rounds=40)
+    b = P.Engine(G, blocks=B, sims=S, dtype=P.NET_BF16, threads=threads, max_game_rounds=40)
+    a.set_weights(T.make_net_flat(B, seed=31, perturb_bn=True))
+    b.set_weights(T.make_net_flat(B, seed=32, perturb_bn=True))
+    a.arena_set_opponent(b)
+    a.arena_collect_samples(True)
+    k = (P.PLAYER_ALPHAZERO_B, P.PLAYER_ALPHAZERO) if b_first else (P.PLAYER_ALPHAZERO, P.PLAYER_ALPHAZERO_B)
+    res, (n, st, rd, fin) = run_arena(a, k[0], k[1], 10 ** 6, per_slot, True, base)
+    assert (n == per_slot).all() and a.counters()["errors"] == 0 and a.counters()["nodes_dropped"] == 0
+    recs = a.drain()
+
+    def make_eval(eng):
+        @T.EVAL_FN
+        def f(ctx, in88, pi, v):
+            x = np.ctypeslib.as_array(in88, shape=(88,)).copy()[None]
+            p, vv = eng.predict(x)
+            C.memmove(pi, p.ctypes.data, 43 * 4)
+            v[0] = float(vv[0])
+        return f
+
+    ea, eb = make_eval(a), make_eval(b)
+    cfg = T.default_settings(mcts_simulations=S, mcts_threads=threads, max_game_rounds=40)
+    tot = np.zeros(6, np.int64)
+    blob = recs.tobytes()
+    nrec = 0
+    for g in range(G):
+        r6, ost, ord_, ofin, orec = T.orc_play_games2(k[0], k[1], per_slot, True, base + g, cfg, ea, eb)
+        assert (st[g, :per_slot] == ost).all(), (g, st[g], ost)
+        assert (rd[g, :per_slot] == ord_).all(), g
+        assert (fin[g, :per_slot][:, FM] == ofin[:, FM]).all(), g
+        tot += np.array(r6)
+        for gi, game in enumerate(orec):   # a finished game's records are flushed contiguously, z filled in
+            assert len(game) > 0 and set(np.unique(game[:, 0])) == {0, 1}, (g, gi)   # both players contributed
+            z = game[:, 89:93].copy().view(np.float32).reshape(-1)
+            want_z = np.where(ost[gi] == -2, 0.0, np.where(game[:, 0] == ost[gi], 1.0, -1.0))
+            assert (z == want_z).all(), (g, gi)
+            assert game.tobytes() in blob, (g, gi)
+            nrec += len(game)
+    assert nrec == len(recs)
+    assert [res["count"], res["draw"], res["win"][0], res["win_and_started"][0], res["win"][1], res["win_and_started"][1]] == list(tot)
+    a.arena_set_opponent(None)
+    a.close(); b.close()

@@ -54,14 +54,14 @@ def test_trim_and_acceptance_rules():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("trainer", ["native", "torch"])
-def test_one_learn_iteration_end_to_end(tmp_path, trainer):
+@pytest.mark.parametrize("trainer,arena", [("native", "device"), ("native", "host")])
+def test_one_learn_iteration_end_to_end(tmp_path, trainer, arena):
     L = learn_mod()
     cwd = os.getcwd()
     os.chdir(tmp_path)
     try:
         a = argparse.Namespace(ti=1, tg=8, mcts=6, gpu_games=8, blocks=1, e=2, bs=64, cg=4, ct=0.0, s=1024 * 512,
-                               seed=77, dtype="bf16", device=0, trainer=trainer)
+                               seed=77, dtype="bf16", device=0, trainer=trainer, arena=arena, include_compare_samples=1)
         out = L.learn(a, log=lambda *_: None)
     finally:
         os.chdir(cwd)
@@ -78,6 +78,19 @@ def test_one_learn_iteration_end_to_end(tmp_path, trainer):
     raw = open(tmp_path / "data/training_samples.bin", "rb").read()
     n = int(np.frombuffer(raw[:8], np.uint64)[0])
     assert len(raw) == 8 + n * 265 and n == out[0]["samples"]
+
+
+@pytest.mark.gpu
+def test_learn_cli_with_the_pytorch_cross_check_step(tmp_path):
+    """`--trainer torch` (train.py, PyTorch-ROCm autograd) in a fresh process: torch's HIP runtime must come up before the
+    C-ABI library's, which a test process that already created engines cannot guarantee"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "alphazero-risk_amd", "learn.py"), "--ti", "1", "--tg", "8", "--mcts", "6",
+                        "--gpu-games", "8", "--blocks", "1", "-e", "1", "--bs", "64", "--cg", "4", "--ct", "0", "--trainer", "torch"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "Loss Policy / Value" in r.stdout and "Model improved" in r.stdout
 
 
 @pytest.mark.gpu
