@@ -87,22 +87,78 @@ __device__ __forceinline__ float plane_value(const uint8_t* in88, int pos, int c
     }
 }
 
-// byte offset (row part) of the LDS row a lane reads for board-cell info `ri` under tap (dy,dx); rows outside the
-// board (or padding rows of the last M tile) read the zero row.  ri = y | x << 4 | row << 8 (y = 15 for padding).
-__device__ __forceinline__ int tap_row(int ri, int dy, int dx, int zero_row)
+// ---------------------------------------------------------------------------------------------------------------
+// Row order inside a workgroup.  A 3x3 SAME conv on the 7x6 board has 304 valid (cell, tap) pairs of 378: a fifth of a
+// dense tiling's MFMAs multiply the zero row.  Cells are therefore ordered by border class so that whole 16-row MFMA
+// tiles are out of board for a tap and both the MFMAs and the LDS fragment reads of that (tile, tap) are skipped:
+//   3 boards (126 cells, 8 tiles):  tile 0 = 16 cells with y = 0 (no dy = -1 taps), tile 1 = 16 cells with y = 6 (no
+//     dy = +1), tile 2 = the 15 cells x = 0, y = 1..5 + 1 pad row (no dx = -1), tile 3 = the 15 cells x = 5 (no dx = +1),
+//     tiles 4..7 = the 2 + 2 left-over y = 0 / y = 6 cells and the 60 interior cells          -> 12 of 72 tile-taps skipped
+//   2 boards (84 cells, 6 tiles):   tile 0 = 12 cells y = 0 + 4 pad rows, tile 1 = 12 cells y = 6 + 4 pad rows,
+//     tiles 2..5 = the other 60 cells + 4 pad rows                                             -> 6 of 54 skipped
+//   1 board: identity (that shape is bound by the weight stream, not by the MFMA pipe).
+// The skipped products are exact zeros, so the results do not change.  row_of() is the only definition of the order; the
+// kernel derives its LDS tables (cell -> row, row -> cell) from it.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ int row_of(int b, int pos)
+{
+    const int y = pos / 6, x = pos - y * 6;
+    if constexpr (NB == 3) {
+        if (y == 0) { const int q = b * 6 + x; return q < 16 ? q : 64 + (q - 16); }
+        if (y == 6) { const int q = b * 6 + x; return q < 16 ? 16 + q : 66 + (q - 16); }
+        if (x == 0) return 32 + b * 5 + (y - 1);
+        if (x == 5) return 48 + b * 5 + (y - 1);
+        return 68 + b * 20 + (y - 1) * 4 + (x - 1);
+    } else if constexpr (NB == 2) {
+        if (y == 0) return b * 6 + x;
+        if (y == 6) return 16 + b * 6 + x;
+        return 32 + b * 30 + (y - 1) * 6 + x;
+    } else {
+        return b * 42 + pos;
+    }
+}
+// is row r a board cell (not one of the pad rows of the order above)?
+template <int NB>
+__device__ __forceinline__ bool row_valid(int r)
+{
+    if constexpr (NB == 3) return r != 47 && r != 63;
+    else if constexpr (NB == 2) return r < 32 ? (r & 15) < 12 : r < 92;
+    else return r < 42;
+}
+// bit mt set = M tile mt has no in-board cell for this tap
+template <int NB>
+constexpr uint32_t skip_mask(int tap)
+{
+    if (tap < 0 || tap > 8) return 0xffffffffu;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    uint32_t m = 0;
+    if (NB >= 2) m |= (dy == -1 ? 1u : 0u) | (dy == 1 ? 2u : 0u);
+    if (NB == 3) m |= (dx == -1 ? 4u : 0u) | (dx == 1 ? 8u : 0u);
+    return m;
+}
+
+// LDS row a lane reads for cell info `ri` (y | x << 4 | board << 8; 0xffff for a pad row) under tap (dy,dx); taps
+// outside the board read the zero row
+__device__ __forceinline__ int tap_row(int ri, int dy, int dx, const uint8_t* __restrict__ rowof, int zero_row)
 {
     const int y = (ri & 15) + dy, x = ((ri >> 4) & 15) + dx;
     const bool ok = (unsigned)y < 7u && (unsigned)x < 6u;
-    return ok ? (ri >> 8) + dy * 6 + dx : zero_row;
+    const int cell = ok ? ((ri >> 8) & 3) * 42 + y * 6 + x : 0;
+    const int r = rowof[cell];
+    return ok ? r : zero_row;
 }
 
 template <int NB>
 struct Geo {
     static constexpr int ROWS = 42 * NB;
     static constexpr int MT = (ROWS + 15) / 16;
-    static constexpr int BUF = (ROWS + 1) * ROWB;   // one activation buffer incl. its zero row
+    static constexpr int ZR = MT * 16;              // index of the shared zero row
+    static constexpr int BUF = (ZR + 1) * ROWB;     // one activation buffer incl. its zero row
     static constexpr int IN88_OFF = 2 * BUF;        // NB x 96 B of NNInputData images
-    static constexpr int LDS_BYTES = 2 * BUF + NB * 96;
+    static constexpr int ROWOF_OFF = IN88_OFF + NB * 96;   // u8 [NB * 42 (+ pad to 128)]: cell -> row
+    static constexpr int ROWCELL_OFF = ROWOF_OFF + 128;    // u16 [MT * 16]: row -> y | x << 4 | board << 8, 0xffff = pad
+    static constexpr int LDS_BYTES = ROWCELL_OFF + 2 * MT * 16;
 };
 
 constexpr size_t KSTRIDE = FRAGS_PER_KSTEP * 64;  // s16x8 units between consecutive k-steps
@@ -133,31 +189,42 @@ template <> struct BnConst<false> { typedef float type; };           // 1 channe
 
 // one tap = 8 k-steps against ring slots SB .. SB+7.  `wb` is the wave-UNIFORM byte pointer to the current
 // k-step's 16-KiB fragment block (advanced with scalar adds); `loff` is this lane's byte offset inside a block.
-template <int MT, int NT, int RT, int SB>
+// SK / SKN: skip_mask of this tap / of the tap whose first fragments are prefetched at the end (all ones = none)
+template <int MT, int NT, int RT, int SB, uint32_t SK, uint32_t SKN>
 __device__ __forceinline__ void conv_tap(const uint8_t* IN, int tap, const char* __restrict__& wb, uint32_t loff,
                                          s16x8 (&bq)[RT * 8][NT], f32x4 (&acc)[MT][NT], s16x8 (&a)[2][MT], int (&aoff)[MT],
-                                         const int (&rinfo)[MT], int g16, int zero_row)
+                                         const int (&rinfo)[MT], int g16, const uint8_t* __restrict__ rowof, int zero_row)
 {
     const int ntap = tap < 8 ? tap + 1 : 8;
     const int ndy = ntap / 3 - 1, ndx = ntap % 3 - 1;
     int noff[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++) noff[mt] = tap_row(rinfo[mt], ndy, ndx, zero_row) * ROWB + g16;
-#pragma unroll
     for (int ks = 0; ks < KS_PER_TAP; ks++) {
         const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks == KS_PER_TAP - 2) {  // the next tap's rows, one k-step before they are needed (short live range)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+                if (!((SKN >> mt) & 1u)) {
+                    // (3-board tile: at the 256-VGPR limit the cell info is re-read from LDS instead of held in registers)
+                    const int ri = MT == 8 ? (int)reinterpret_cast<const uint16_t*>(rowof + 128)[mt * 16 + (threadIdx.x & 15)] : rinfo[mt];
+                    noff[mt] = tap_row(ri, ndy, ndx, rowof, zero_row) * ROWB + g16;
+                }
+        }
         // (1) LDS reads of the NEXT k-step's A fragments go out first ...
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-            a[nxt][mt] = ks < KS_PER_TAP - 1 ? *reinterpret_cast<const s16x8*>(IN + aoff[mt] + (ks + 1) * 64)
-                                             : *reinterpret_cast<const s16x8*>(IN + noff[mt]);
+        for (int mt = 0; mt < MT; mt++) {
+            if (ks < KS_PER_TAP - 1) { if (!((SK >> mt) & 1u)) a[nxt][mt] = *reinterpret_cast<const s16x8*>(IN + aoff[mt] + (ks + 1) * 64); }
+            else if (!((SKN >> mt) & 1u)) a[nxt][mt] = *reinterpret_cast<const s16x8*>(IN + noff[mt]);
+        }
         __builtin_amdgcn_sched_barrier(0);
         // (2) ... and fly under this k-step's MFMAs; then the freed ring slot is refilled one ring ahead
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int nt = 0; nt < NT; nt++)
-                if constexpr (Swap<MT>::value)
+                if ((SK >> mt) & 1u) {
+                    // every row of this tile is out of board for this tap: the products are exact zeros
+                } else if constexpr (Swap<MT>::value)
                     // weights as the MFMA "A" operand, activations as "B": D[channel][cell], so a lane ends up with 4
                     // CONSECUTIVE CHANNELS of one board cell (row = 4*(lane>>4)+j, col = lane&15) -> 8-byte LDS stores
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[SB + ks][nt]),
@@ -172,7 +239,8 @@ __device__ __forceinline__ void conv_tap(const uint8_t* IN, int tap, const char*
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++) aoff[mt] = noff[mt];
+    for (int mt = 0; mt < MT; mt++)
+        if (!((SKN >> mt) & 1u)) aoff[mt] = noff[mt];
 }
 
 // One 3x3 conv layer F->F: acc[mt][nt] = sum over 9 taps x 256 channels (72 k-steps of 32).
@@ -185,7 +253,7 @@ __device__ __forceinline__ void conv_tap(const uint8_t* IN, int tap, const char*
 template <int MT, int NT, int RT, int PAR>
 __device__ __forceinline__ void conv_tower_layer(const uint8_t* IN, const char* __restrict__& wb, uint32_t loff,
                                                  s16x8 (&bq)[RT * 8][NT], f32x4 (&acc)[MT][NT], const int (&rinfo)[MT], int g16,
-                                                 int zero_row, const float* __restrict__ fs, typename BnConst<Swap<MT>::value>::type (&sc)[NT],
+                                                 const uint8_t* __restrict__ rowof, int zero_row, const float* __restrict__ fs, typename BnConst<Swap<MT>::value>::type (&sc)[NT],
                                                  typename BnConst<Swap<MT>::value>::type (&sh)[NT])
 {
 #pragma unroll
@@ -194,9 +262,12 @@ __device__ __forceinline__ void conv_tower_layer(const uint8_t* IN, const char* 
         for (int nt = 0; nt < NT; nt++) acc[mt][nt] = f32x4{0, 0, 0, 0};
     int aoff[MT];
     s16x8 a[2][MT];
+    constexpr int NBX = MT == 8 ? 3 : MT == 6 ? 2 : 1;   // boards per workgroup of this tile count
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
-        aoff[mt] = tap_row(rinfo[mt], -1, -1, zero_row) * ROWB + g16;
+        if ((skip_mask<NBX>(0) >> mt) & 1u) { aoff[mt] = zero_row * ROWB + g16; continue; }
+        const int ri = MT == 8 ? (int)reinterpret_cast<const uint16_t*>(rowof + 128)[mt * 16 + (threadIdx.x & 15)] : rinfo[mt];
+        aoff[mt] = tap_row(ri, -1, -1, rowof, zero_row) * ROWB + g16;
         a[0][mt] = *reinterpret_cast<const s16x8*>(IN + aoff[mt]);
     }
     // this layer's folded BN (4 consecutive channels per lane and tile) is requested one tap before the epilogue:
@@ -215,15 +286,17 @@ __device__ __forceinline__ void conv_tower_layer(const uint8_t* IN, const char* 
     };
     if constexpr (RT == 1) {
         load_bn();  // (register allocation at the 256-VGPR limit of the 3-board tile is best with the early load)
-        for (int tap = 0; tap < 9; tap++) conv_tap<MT, NT, 1, 0>(IN, tap, wb, loff, bq, acc, a, aoff, rinfo, g16, zero_row);
+#define AZR_TAP(T) conv_tap<MT, NT, 1, 0, skip_mask<NBX>(T), skip_mask<NBX>(T + 1)>(IN, T, wb, loff, bq, acc, a, aoff, rinfo, g16, rowof, zero_row)
+        AZR_TAP(0); AZR_TAP(1); AZR_TAP(2); AZR_TAP(3); AZR_TAP(4); AZR_TAP(5); AZR_TAP(6); AZR_TAP(7); AZR_TAP(8);
+#undef AZR_TAP
     } else {
         constexpr int S0 = PAR ? 8 : 0, S1 = PAR ? 0 : 8;
         for (int tap = 0; tap < 8; tap += 2) {
-            conv_tap<MT, NT, 2, S0>(IN, tap, wb, loff, bq, acc, a, aoff, rinfo, g16, zero_row);
-            conv_tap<MT, NT, 2, S1>(IN, tap + 1, wb, loff, bq, acc, a, aoff, rinfo, g16, zero_row);
+            conv_tap<MT, NT, 2, S0, 0u, 0u>(IN, tap, wb, loff, bq, acc, a, aoff, rinfo, g16, rowof, zero_row);
+            conv_tap<MT, NT, 2, S1, 0u, 0u>(IN, tap + 1, wb, loff, bq, acc, a, aoff, rinfo, g16, rowof, zero_row);
         }
         load_bn();
-        conv_tap<MT, NT, 2, S0>(IN, 8, wb, loff, bq, acc, a, aoff, rinfo, g16, zero_row);
+        conv_tap<MT, NT, 2, S0, 0u, 0u>(IN, 8, wb, loff, bq, acc, a, aoff, rinfo, g16, rowof, zero_row);
     }
 }
 
@@ -236,10 +309,12 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
                                            unsigned long long* __restrict__ diag, const int* __restrict__ slot_map)
 {
     using G = Geo<NB>;
-    constexpr int ROWS = G::ROWS, MT = G::MT, THREADS = 1024 / NT, WCOLS = NT * 16;
+    constexpr int ROWS = G::ROWS, MT = G::MT, ZR = G::ZR, THREADS = 1024 / NT, WCOLS = NT * 16;
     uint8_t* bufX = lds;
     uint8_t* bufT = lds + G::BUF;
     uint8_t* in_l = lds + G::IN88_OFF;
+    uint8_t* rowof = lds + G::ROWOF_OFF;                                        // cell (board * 42 + pos) -> row
+    uint16_t* rowcell = reinterpret_cast<uint16_t*>(lds + G::ROWCELL_OFF);      // row -> y | x << 4 | board << 8
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, g = lane >> 4;
     // clock diagnostic (azr_debug_tower_clock): shader-clock and 100 MHz real-time stamps around the whole tower of
@@ -254,15 +329,31 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
         in_l[i] = (board0 + b < n && o < 88) ? in88[(size_t)slot * in_stride + o] : (uint8_t)0;
     }
     for (int i = tid; i < ROWB / 4; i += THREADS) {
-        reinterpret_cast<uint32_t*>(bufX + ROWS * ROWB)[i] = 0;
-        reinterpret_cast<uint32_t*>(bufT + ROWS * ROWB)[i] = 0;
+        reinterpret_cast<uint32_t*>(bufX + ZR * ROWB)[i] = 0;
+        reinterpret_cast<uint32_t*>(bufT + ZR * ROWB)[i] = 0;
+    }
+    // pad rows of the row order hold zeros too (their accumulator rows are never stored, but they are MFMA operands)
+    for (int i = tid; i < (ZR - ROWS) * (ROWB / 4); i += THREADS) {
+        int pr = i / (ROWB / 4), k = 0;
+        for (int r = 0; r < ZR; r++)
+            if (!row_valid<NB>(r)) { if (k == pr) { pr = r; break; } k++; }
+        reinterpret_cast<uint32_t*>(bufX + pr * ROWB)[i % (ROWB / 4)] = 0;
+        reinterpret_cast<uint32_t*>(bufT + pr * ROWB)[i % (ROWB / 4)] = 0;
+    }
+    for (int i = tid; i < ZR; i += THREADS) rowcell[i] = 0xffffu;
+    __syncthreads();
+    for (int i = tid; i < ROWS; i += THREADS) {
+        const int b = i / 42, pos = i - b * 42, r = row_of<NB>(b, pos);
+        rowof[i] = (uint8_t)r;
+        rowcell[r] = (uint16_t)((pos / 6) | ((pos % 6) << 4) | (b << 8));
     }
     __syncthreads();
-    // stem features: bufT as [ROWS + 1][16] bf16 (row ROWS = zero row); planes 13..15 are zero
-    for (int i = tid; i < (ROWS + 1) * 16; i += THREADS) {
+    // stem features: bufT as [ZR + 1][16] bf16 (row ZR = zero row); planes 13..15 are zero
+    for (int i = tid; i < (ZR + 1) * 16; i += THREADS) {
         const int r = i >> 4, c = i & 15;
         float v = 0.0f;
-        if (r < ROWS) v = plane_value(in_l + (r / 42) * 96, r % 42, c);
+        const int ci = r < ZR ? rowcell[r] : 0xffff;
+        if (ci != 0xffff) v = plane_value(in_l + (ci >> 8) * 96, (ci & 15) * 6 + ((ci >> 4) & 15), c);
         reinterpret_cast<uint16_t*>(bufT)[i] = bf_rne(v);
     }
     __syncthreads();
@@ -270,11 +361,7 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
     // ---- per-lane geometry of the rows this lane feeds as MFMA A operand (row = mt*16 + m)
     int rinfo[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++) {
-        const int r = mt * 16 + m;
-        const int pos = r % 42, y = pos / 6, x = pos % 6;
-        rinfo[mt] = r < ROWS ? (y | (x << 4) | (r << 8)) : (15 | (15 << 4) | (ROWS << 8));
-    }
+    for (int mt = 0; mt < MT; mt++) rinfo[mt] = rowcell[mt * 16 + m];   // 0xffff (y = x = 15) for a pad row
     f32x4 acc[MT][NT];
 
     // ---- start the weight ring: the first ring of k-steps of layer 0 flies while the stem runs
@@ -303,7 +390,7 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
             for (int nt = 0; nt < NT; nt++) b[nt] = wp[(size_t)ks * FRAGS_PER_KSTEP * 64 + nt * 64];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
-                const int row = tap < 9 ? tap_row(rinfo[mt], dy, dx, ROWS) : ROWS;
+                const int row = tap < 9 ? tap_row(rinfo[mt], dy, dx, rowof, ZR) : ZR;
                 const s16x8 av = *reinterpret_cast<const s16x8*>(bufT + row * FROWB + (g & 1) * 16);
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++)
@@ -318,8 +405,8 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             const int r = mt * 16 + m;
-            if (r < ROWS) {
-                const int y = (r % 42) / 6;
+            if (rinfo[mt] != 0xffff) {
+                const int y = rinfo[mt] & 15;
                 const float sc = fold[y], sh = fold[7 + y];
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
@@ -341,8 +428,9 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int r = mt * 16 + g * 4 + j;
-                    if (r < ROWS) {
-                        const int y = (r % 42) / 6;
+                    const int ci = rowcell[r];
+                    if (ci != 0xffff) {
+                        const int y = ci & 15;
                         const float sc = fold[y], sh = fold[7 + y];
 #pragma unroll
                         for (int nt = 0; nt < NT; nt++) {
@@ -365,7 +453,7 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int r = mt * 16 + g * 4 + j;
-                    if (r < ROWS) {
+                    if (row_valid<NB>(r)) {
 #pragma unroll
                         for (int nt = 0; nt < NT; nt++) {
                             uint16_t* o = reinterpret_cast<uint16_t*>(OUT + r * ROWB) + wave * WCOLS + nt * 16 + m;
@@ -380,7 +468,7 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             const int r = mt * 16 + m;
-            if (r < ROWS) {
+            if (row_valid<NB>(r)) {
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
                     uint2* o = reinterpret_cast<uint2*>(OUT + r * ROWB + (wave * WCOLS + nt * 16 + g * 4) * 2);
@@ -402,10 +490,10 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
     for (int blk = 0; blk < blocks; blk++) {
         bn_t sc[NT], sh[NT];
         const float* fs = fold + 14 + (size_t)(2 * blk) * 2 * NF + wave * WCOLS + (Swap<MT>::value ? g * 4 : m);
-        conv_tower_layer<MT, NT, RT, 0>(bufX, wb, loff, bq, acc, rinfo, g16, ROWS, fs, sc, sh);
+        conv_tower_layer<MT, NT, RT, 0>(bufX, wb, loff, bq, acc, rinfo, g16, rowof, ZR, fs, sc, sh);
         epilogue(false, bufT, sc, sh);
         __syncthreads();
-        conv_tower_layer<MT, NT, RT, 1>(bufT, wb, loff, bq, acc, rinfo, g16, ROWS, fs + 2 * NF, sc, sh);
+        conv_tower_layer<MT, NT, RT, 1>(bufT, wb, loff, bq, acc, rinfo, g16, rowof, ZR, fs + 2 * NF, sc, sh);
         epilogue(true, bufX, sc, sh);
         __syncthreads();
     }
@@ -429,7 +517,7 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
         float* logit = hid + NB * 256;                  // [NB][64]
         for (int idx = tid; idx < NB * 126; idx += THREADS) {  // 42 cells x {pi0, pi1, v} per board
             const int bb = idx / 126, t = idx % 126, pos = t / 3, c = t % 3;
-            const uint16_t* x = reinterpret_cast<const uint16_t*>(bufX + (bb * 42 + pos) * ROWB);
+            const uint16_t* x = reinterpret_cast<const uint16_t*>(bufX + rowof[bb * 42 + pos] * ROWB);
             float sacc = 0.0f;
             if (c < 2) for (int ci = 0; ci < NF; ci++) sacc = fmaf(bf2f(x[ci]), wpi[ci * 2 + c], sacc);
             else for (int ci = 0; ci < NF; ci++) sacc = fmaf(bf2f(x[ci]), wv[ci], sacc);

@@ -188,7 +188,7 @@ def main():
                          # HBM-side bytes per launch from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction),
                          # profiles/r01_final_pmc_fetch_write_g256_s100_t{1,2}_b20.txt — measured for exactly these configurations
                          "traffic": {(256, 1, 20, "bf16"): (2 * 186413.07 + 56.0) * 1024,
-                                     (256, 2, 20, "bf16"): (2 * 185944.59 + 96.0) * 1024}.get(
+                                     (256, 2, 20, "bf16"): (2 * 186194.60 + 96.0) * 1024}.get(
                                          (a.games, a.threads, a.blocks, a.dtype))},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -53,7 +53,11 @@ def test_misuse_returns_error_codes(tmp_path):
     # arena kinds: AlphaZero vs AlphaZero in one engine is refused with a clear message
     with pytest.raises(P.AzrError) as e:
         eng.arena_start(P.PLAYER_ALPHAZERO, P.PLAYER_ALPHAZERO, 4)
-    assert "two trees" in str(e.value)
+    assert "one tree each" in str(e.value)
+    # ... the opponent player without an opponent handle too
+    with pytest.raises(P.AzrError) as e:
+        eng.arena_start(P.PLAYER_ALPHAZERO, P.PLAYER_ALPHAZERO_B, 4)
+    assert e.value.code == 7 and "azr_arena_set_opponent_net" in str(e.value)
     eng.close()
 
 
