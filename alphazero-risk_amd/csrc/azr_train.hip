@@ -228,6 +228,21 @@ __device__ __forceinline__ uint32_t bf_rne_bits(float f)
     const uint32_t u = __float_as_uint(f);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
+__device__ __forceinline__ void split_store4(const float (&v)[4], size_t i4, uint16_t* p0, uint16_t* p1, uint16_t* p2)
+{
+    uint32_t h[4], m[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        h[j] = bf_rne_bits(v[j]);
+        const float r1 = v[j] - __uint_as_float(h[j] << 16);
+        m[j] = bf_rne_bits(r1);
+        l[j] = bf_rne_bits(r1 - __uint_as_float(m[j] << 16));
+    }
+    reinterpret_cast<uint2*>(p0)[i4] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    reinterpret_cast<uint2*>(p1)[i4] = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+    if (p2) reinterpret_cast<uint2*>(p2)[i4] = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+
 // x[n] fp32 -> NP bf16 part arrays (n % 4 == 0)
 template <int NP>
 __global__ __launch_bounds__(256) void t_split(const float* __restrict__ x, size_t n4, uint16_t* __restrict__ p0, uint16_t* __restrict__ p1,
@@ -526,6 +541,10 @@ __global__ __launch_bounds__(256) void t_add(float* __restrict__ a, const float*
 // =====================================================================================================================
 constexpr int NG = 7;  // stem groups
 
+__device__ __forceinline__ uint32_t bf_rne_bits(float f);
+// the bf16 parts of 4 consecutive values (see t_split), written as one 8-byte store per part
+__device__ __forceinline__ void split_store4(const float (&v)[4], size_t i4, uint16_t* p0, uint16_t* p1, uint16_t* p2);
+
 // sum of v over the 4 row-groups q = t >> 8 of a 1024-thread block, per channel c = t & 255 (result valid where q == 0)
 __device__ __forceinline__ double reduce_q4(double v, double* sh)
 {
@@ -535,6 +554,20 @@ __device__ __forceinline__ double reduce_q4(double v, double* sh)
     __syncthreads();
     if (t < 256) v = sh[t] + sh[t + 256] + sh[t + 512] + sh[t + 768];
     return v;
+}
+
+// sum of v over the 32 row-groups q = t >> 5 of a 1024-thread block, per channel slot t & 31 (valid where q == 0)
+__device__ __forceinline__ double reduce_q32(double v, double* sh)
+{
+    const int t = threadIdx.x;
+    __syncthreads();
+    sh[t] = v;
+    __syncthreads();
+    for (int o = 512; o >= 32; o >>= 1) {
+        if (t < o) sh[t] += sh[t + o];
+        __syncthreads();
+    }
+    return sh[t & 31];
 }
 
 __device__ __forceinline__ double block_sum_1024(double v, double* sh)
@@ -592,12 +625,15 @@ __global__ __launch_bounds__(1024) void t_bn_finalize(const double* __restrict__
                                                       float* __restrict__ istd, float* __restrict__ bn /* g|b|mu|var */)
 {
     __shared__ double sh[1024];
-    const int c = threadIdx.x & 255, q = threadIdx.x >> 8;
+    int c = threadIdx.x & 255, q = threadIdx.x >> 8;
     if constexpr (!STEM) {
+        // grid of 8 blocks: block = 32 channels x 32 groups of partial rows
+        c = blockIdx.x * 32 + (threadIdx.x & 31);
+        q = threadIdx.x >> 5;
         double s = 0.0, ss = 0.0;
-        for (int b = q; b < R; b += 4) { s += part[((size_t)b * 2 + 0) * NF + c]; ss += part[((size_t)b * 2 + 1) * NF + c]; }
-        s = reduce_q4(s, sh);
-        ss = reduce_q4(ss, sh);
+        for (int b = q; b < R; b += 32) { s += part[((size_t)b * 2 + 0) * NF + c]; ss += part[((size_t)b * 2 + 1) * NF + c]; }
+        s = reduce_q32(s, sh);
+        ss = reduce_q32(ss, sh);
         if (q == 0) {
             const double mu = s / count, var = fmax(ss / count - mu * mu, 0.0);
             mean[c] = (float)mu;
@@ -628,7 +664,8 @@ __global__ __launch_bounds__(1024) void t_bn_finalize(const double* __restrict__
 // A = relu(gamma * (Y - mean) * istd + beta (+ S))
 template <bool STEM>
 __global__ __launch_bounds__(256) void t_bn_apply(const float* __restrict__ Y, const float* __restrict__ mean, const float* __restrict__ istd,
-                                                  const float* __restrict__ bn, const float* __restrict__ S, float* __restrict__ A, int M)
+                                                  const float* __restrict__ bn, const float* __restrict__ S, float* __restrict__ A, int M,
+                                                  uint16_t* __restrict__ p0, uint16_t* __restrict__ p1, uint16_t* __restrict__ p2)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
     if (i >= (size_t)M * (NF / 4)) return;
@@ -645,6 +682,7 @@ __global__ __launch_bounds__(256) void t_bn_apply(const float* __restrict__ Y, c
         o[j] = v > 0.0f ? v : 0.0f;
     }
     reinterpret_cast<float4*>(A)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if (p0) split_store4(o, i, p0, p1, p2);  // operand parts of the next layer's forward GEMM
 }
 
 // backward stage 1: dz = dOut * (Apost > 0); partial sums of dz and dz * xhat
@@ -699,12 +737,14 @@ template <bool STEM>
 __global__ __launch_bounds__(1024) void t_bn_bwd_finalize(const double* __restrict__ part, int R, float* __restrict__ gbn, float* __restrict__ sums)
 {
     __shared__ double sh[1024];
-    const int c = threadIdx.x & 255, q = threadIdx.x >> 8;
+    int c = threadIdx.x & 255, q = threadIdx.x >> 8;
     if constexpr (!STEM) {
+        c = blockIdx.x * 32 + (threadIdx.x & 31);
+        q = threadIdx.x >> 5;
         double s = 0.0, sx = 0.0;
-        for (int b = q; b < R; b += 4) { s += part[((size_t)b * 2 + 0) * NF + c]; sx += part[((size_t)b * 2 + 1) * NF + c]; }
-        s = reduce_q4(s, sh);
-        sx = reduce_q4(sx, sh);
+        for (int b = q; b < R; b += 32) { s += part[((size_t)b * 2 + 0) * NF + c]; sx += part[((size_t)b * 2 + 1) * NF + c]; }
+        s = reduce_q32(s, sh);
+        sx = reduce_q32(sx, sh);
         if (q == 0) {
             gbn[c] = (float)sx;
             gbn[NF + c] = (float)s;
@@ -731,7 +771,7 @@ __global__ __launch_bounds__(256) void t_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ Y, const float* __restrict__ mean,
                                                       const float* __restrict__ istd, const float* __restrict__ bn,
                                                       const float* __restrict__ sums, float inv_count, float* __restrict__ dY,
-                                                      float* __restrict__ dZ, int M)
+                                                      float* __restrict__ dZ, int M, uint16_t* __restrict__ p0, uint16_t* __restrict__ p1)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)M * (NF / 4)) return;
@@ -750,6 +790,7 @@ __global__ __launch_bounds__(256) void t_bn_bwd_apply(const float* __restrict__ 
     }
     reinterpret_cast<float4*>(dY)[i] = make_float4(o[0], o[1], o[2], o[3]);
     if (dZ) reinterpret_cast<float4*>(dZ)[i] = make_float4(z[0], z[1], z[2], z[3]);
+    if (p0) split_store4(o, i, p0, p1, nullptr);  // operand parts of the two gradient GEMMs
 }
 
 // =====================================================================================================================
@@ -1210,17 +1251,20 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     gemm<false, false, 64>(st, c->col0, KS, c->wpad, NF, Yl(0), NF, M, NF, KS);
     hipLaunchKernelGGL((t_bn_stats<true>), dim3(R), dim3(1024), 0, st, Yl(0), M, c->part);
     hipLaunchKernelGGL((t_bn_finalize<true>), dim3(1), dim3(1024), 0, st, c->part, R, (double)BS * 6 * NF, c->mean, c->istd, w + OFF_STEM_BN);
-    hipLaunchKernelGGL((t_bn_apply<true>), dim3(g4), dim3(256), 0, st, Yl(0), c->mean, c->istd, w + OFF_STEM_BN, (const float*)nullptr, Al(0), M);
+    uint16_t* const nil16 = nullptr;
+    // (each layer's normalise kernel also writes the three bf16 parts of its output: the next conv's A operand)
+    hipLaunchKernelGGL((t_bn_apply<true>), dim3(g4), dim3(256), 0, st, Yl(0), c->mean, c->istd, w + OFF_STEM_BN, (const float*)nullptr, Al(0), M,
+                       sb ? c->ap[0] : nil16, c->ap[1], c->ap[2]);
     for (int l = 1; l < c->L; l++) {
         float* bn = Wl(l) + (size_t)9 * NF * NF;
         const float* S = (l % 2 == 0) ? Al(l - 2) : nullptr;  // second conv of a block adds the block input
         if (sb) {  // conv = implicit im2col x W, 6-pass split bf16 (fp32-exact products)
-            hipLaunchKernelGGL((t_split<3>), dim3(g4), dim3(256), 0, st, Al(l - 1), act / 4, c->ap[0], c->ap[1], c->ap[2]);
             gemm_sb<false, false, 64, 1, 0, 3>(st, Parts{{c->ap[0], c->ap[1], c->ap[2]}}, KC, Wp(l), NF, Yl(l), NF, M, NF, KC);
         } else gemm<false, false, 64, 1, 0>(st, Al(l - 1), KC, Wl(l), NF, Yl(l), NF, M, NF, KC);
         hipLaunchKernelGGL((t_bn_stats<false>), dim3(R), dim3(1024), 0, st, Yl(l), M, c->part);
-        hipLaunchKernelGGL((t_bn_finalize<false>), dim3(1), dim3(1024), 0, st, c->part, R, (double)M, c->mean + l * NF, c->istd + l * NF, bn);
-        hipLaunchKernelGGL((t_bn_apply<false>), dim3(g4), dim3(256), 0, st, Yl(l), c->mean + l * NF, c->istd + l * NF, bn, S, Al(l), M);
+        hipLaunchKernelGGL((t_bn_finalize<false>), dim3(8), dim3(1024), 0, st, c->part, R, (double)M, c->mean + l * NF, c->istd + l * NF, bn);
+        hipLaunchKernelGGL((t_bn_apply<false>), dim3(g4), dim3(256), 0, st, Yl(l), c->mean + l * NF, c->istd + l * NF, bn, S, Al(l), M,
+                           (sb && l + 1 < c->L) ? c->ap[0] : nil16, c->ap[1], c->ap[2]);
     }
     const float* H = Al(c->L - 1);
     hipLaunchKernelGGL(t_head_conv, grid1((size_t)M, 4), dim3(256), 0, st, H, hp, c->pv0, M);
@@ -1243,13 +1287,12 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         float* bn = Wl(l) + wn;
         float* gbn = Gl(l) + wn;
         hipLaunchKernelGGL((t_bn_bwd_stats<false>), dim3(R), dim3(1024), 0, st, dOut, Al(l), Yl(l), c->mean + l * NF, c->istd + l * NF, M, c->part);
-        hipLaunchKernelGGL((t_bn_bwd_finalize<false>), dim3(1), dim3(1024), 0, st, c->part, R, gbn, c->sums);
+        hipLaunchKernelGGL((t_bn_bwd_finalize<false>), dim3(8), dim3(1024), 0, st, c->part, R, gbn, c->sums);
         hipLaunchKernelGGL((t_bn_bwd_apply<false>), dim3(g4), dim3(256), 0, st, dOut, Al(l), Yl(l), c->mean + l * NF, c->istd + l * NF, bn, c->sums,
-                           invM, c->dY, second ? c->DS : (float*)nullptr, M);
+                           invM, c->dY, second ? c->DS : (float*)nullptr, M, sb ? c->dyp[0] : nil16, c->dyp[1]);
         // dW = col(input)^T x dY  (implicit im2col, split-K over the M rows)
         if (sb) {
             hipLaunchKernelGGL((t_split<2>), dim3(g4), dim3(256), 0, st, Al(l - 1), act / 4, c->ap[0], c->ap[1], (uint16_t*)nullptr);
-            hipLaunchKernelGGL((t_split<2>), dim3(g4), dim3(256), 0, st, c->dY, act / 4, c->dyp[0], c->dyp[1], (uint16_t*)nullptr);
             gemm_sb<true, false, 128, 1, 0, 2>(st, Parts{{c->ap[0], c->ap[1], nullptr}}, KC, Parts{{c->dyp[0], c->dyp[1], nullptr}}, NF, c->wpart,
                                                NF, KC, NF, M, c->nz, c->kchunk, wn);
         } else gemm<true, false, 128, 1, 0>(st, Al(l - 1), KC, c->dY, NF, c->wpart, NF, KC, NF, M, c->nz, c->kchunk, wn);
@@ -1264,7 +1307,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         hipLaunchKernelGGL((t_bn_bwd_stats<true>), dim3(R), dim3(1024), 0, st, c->G, Al(0), Yl(0), c->mean, c->istd, M, c->part);
         hipLaunchKernelGGL((t_bn_bwd_finalize<true>), dim3(1), dim3(1024), 0, st, c->part, R, g + OFF_STEM_BN, c->sums);
         hipLaunchKernelGGL((t_bn_bwd_apply<true>), dim3(g4), dim3(256), 0, st, c->G, Al(0), Yl(0), c->mean, c->istd, w + OFF_STEM_BN, c->sums,
-                           1.0f / ((float)BS * 6 * NF), c->dY, (float*)nullptr, M);
+                           1.0f / ((float)BS * 6 * NF), c->dY, (float*)nullptr, M, nil16, nil16);
         gemm<true, false>(st, c->col0, KS, c->dY, NF, c->wpart, NF, KS, NF, M, c->nz, c->kchunk, (size_t)KS * NF);
         hipLaunchKernelGGL(t_sum_slices, grid1((size_t)KS * NF, 256), dim3(256), 0, st, c->wpart, c->nz, (size_t)KS * NF, c->gpad);
         hipLaunchKernelGGL(t_stem_unpad, grid1((size_t)9 * 13 * NF, 256), dim3(256), 0, st, c->gpad, g);
