@@ -191,6 +191,17 @@ def main():
                                      (256, 2, 20, "bf16"): (2 * 186194.60 + 96.0) * 1024}.get(
                                          (a.games, a.threads, a.blocks, a.dtype))},
         }
+        # the HBM-side part of a simulation: node reads / backup writes per tree level, leaf record, prior and
+        # node write per evaluation, state + control block per game and pass.  One wavefront walks one game's tree, so
+        # this kernel is bound by dependent-access latency, not by bandwidth: the fraction below says how far from it.
+        lv, ev = levels / max(1, world), evals / max(1, world)
+        tree_bytes = lv * (640 + 64 + 12 + 4) + ev * (96 + 64 + 16 + 176 + 4 + 640 + 8) + a.steps * a.games * (64 + 128) * 2
+        tree_s = prof["tree_ms"] * 1e-3 * a.steps
+        out["tree_step"] = {"bound": "hbm", "kernel": "k_tree_step (select / expand / backup / decision for every game, one wavefront each)",
+                            "achieved": tree_bytes / tree_s / 1e9 if tree_s > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
+                            "frac": tree_bytes / tree_s / 8e12 if tree_s > 0 else 0.0,
+                            "bytes_per_simulation": tree_bytes / max(1.0, sims / max(1, world)), "avg_launch_ms": prof["tree_ms"],
+                            "note": "latency-bound pointer chasing (mean depth %.2f); 4-5 %% of the step" % (levels / max(1, sims))}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.blocks, a.sims, a.threads)
         print(json.dumps(out))

@@ -13,15 +13,17 @@ pytestmark = pytest.mark.gpu
 FM = T.data_field_mask()
 
 
-def test_full_size_selfplay_invariants_and_determinism(orc):
-    """BASELINE configs[1] shape (G=256, S=100, B=20, bf16): two independent engines with the same seeds stay
-    bit-identical (states, RNG streams, counters); every exported state satisfies the reference's consistencyCheck
-    identities; evaluation/simulation counters balance."""
+@pytest.mark.parametrize("G,S,threads,passes", [(256, 100, 1, 450), (256, 100, 2, 300), (2048, 400, 2, 60)])
+def test_full_size_selfplay_invariants_and_determinism(orc, G, S, threads, passes):
+    """BASELINE configs[1] (G=256, S=100; at THREADS_PER_MCTS 1 and at the bench default 2) and configs[2] (G=2048,
+    S=400) shapes, B=20, bf16: two independent engines with the same seeds stay bit-identical (states, RNG streams,
+    counters); every exported state satisfies the reference's consistencyCheck identities; evaluation/simulation
+    counters balance."""
     P = pkg()
-    G, S, B, passes = 256, 100, 20, 450
+    B = 20
     engs = []
     for _ in range(2):
-        e = P.Engine(G, blocks=B, sims=S, dtype=P.NET_BF16)
+        e = P.Engine(G, blocks=B, sims=S, dtype=P.NET_BF16, threads=threads)
         e.init_random(20260002)
         e.selfplay_start(20260001)
         e.selfplay_run(passes)
@@ -32,14 +34,17 @@ def test_full_size_selfplay_invariants_and_determinism(orc):
     ca, cb = a.counters(), b.counters()
     assert ca == cb
     assert ca["errors"] == 0 and ca["nodes_dropped"] == 0
-    # every pass hands exactly one leaf per game to the net: evaluations consumed = G * (passes - 1)
-    assert ca["evaluations"] == G * (passes - 1)
+    # every pass hands one leaf per game and search thread to the net (one per game while a root is being expanded):
+    # at T = 1 evaluations consumed = G * (passes - 1) exactly
+    assert G * (passes - 1) <= ca["evaluations"] <= G * threads * (passes - 1)
+    if threads == 1:
+        assert ca["evaluations"] == G * (passes - 1)
     # evaluations = simulations that ended in a leaf + root expansions; terminal simulations need no evaluation
     assert ca["simulations"] >= ca["evaluations"] - ca["decisions"] - G
-    assert ca["decisions"] >= G * ((passes - 2) // (S + 1)) - G
+    assert ca["decisions"] >= G * ((passes - 2) * threads // (S + threads + 1)) - G
     s = T.OrcState()
     back = np.zeros(160, np.uint8)
-    for g in range(0, G, 3):
+    for g in range(0, G, 3 if G <= 256 else 17):
         orc.orc_state_unpack(C.byref(s), T.ptr(sa[g]))
         assert orc.orc_consistency_check(C.byref(s)) == 0
         orc.orc_state_pack(C.byref(s), T.ptr(back))
