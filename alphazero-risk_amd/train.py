@@ -1,16 +1,18 @@
-"""Train step of the learn loop — PROVISIONAL implementation.
+"""PyTorch cross-check of the optimiser step.
 
-The reference trains through TensorFlow's `optimize` op (python/src/build_graph.py:92-103, driven by
-AlphaZeroNN::train, neural_network/alphazero_nn.cpp:351-410).  This round the optimiser step runs on PyTorch-ROCm
-autograd over the same AZRW flat parameter vector the HIP inference engine uses (SURVEY §7 step 10 allows this as the
-first form); hand-written HIP forward-train / backward / Adam kernels replace it in a later round.  Inference, search and
-self-play never touch this module.  Parity: "unpinned" (no TensorFlow here); the forward pass is checked against the
-oracle's fp32 restatement and the update rule against a NumPy Adam in tests/test_train.py.
+The product's optimiser step is `azr_nn_train` (csrc/azr_train.hip: hand-written HIP forward-train / backward / Adam on
+the AZRW vector).  This module is the same graph — python/src/build_graph.py:54-103, driven by AlphaZeroNN::train,
+neural_network/alphazero_nn.cpp:351-410 — in PyTorch autograd over the same AZRW flat parameter vector.  It is what the
+native step is tested against (tests/test_gpu_train.py, float64 on the CPU), the timing yard-stick of
+tools/train_bench.py (PyTorch-ROCm / MIOpen), and `learn.py --trainer torch`.  Inference, search and self-play never
+touch it.  Parity: "unpinned" (no TensorFlow here); its forward pass is checked against the oracle's fp32 restatement
+and its update rule against a NumPy Adam in tests/test_train.py.
 
 Semantics kept from the reference graph:
   loss = softmax-CE(target pi, logits) [batch mean] + MSE(z, v) [batch mean] + 1e-3 * sum ||kernel||^2
          over the 2B+3 conv kernels and the 3 dense kernels (build_graph.py:30,60,92-98)
-  Adam(lr 1e-3, beta1 .9, beta2 .999, eps 1e-8) (build_graph.py:31,103); BN momentum 0.99, eps 1e-3, batch statistics
+  Adam(lr 1e-3, beta1 .9, beta2 .999, eps 1e-8) (build_graph.py:31,103; torch.optim.Adam places eps slightly
+  differently from tf.train.AdamOptimizer, which the native step follows); BN momentum 0.99, eps 1e-3, batch statistics
   in training; the stem's conv_bn normalises over the board ROW (axis=1, build_graph.py:68)
   per epoch: shuffle, floor(N / BATCH_SIZE) minibatches, epoch-average policy / value loss (alphazero_nn.cpp:366-408)
 """

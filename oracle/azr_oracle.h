@@ -129,7 +129,7 @@ void orc_mcts_destroy(orc_mcts* m);
 void orc_mcts_clear(orc_mcts* m);
 void orc_mcts_trim(orc_mcts* m);
 int orc_mcts_node_count(const orc_mcts* m);
-/* AlphaZeroMCTS::simulate at t = 1; returns ORC_OK or an error */
+/* AlphaZeroMCTS::simulate with cfg.mcts_threads lock-stepped search threads; returns ORC_OK or an error */
 int orc_mcts_simulate(orc_mcts* m, const orc_state* root, orc_rng* r, orc_eval_fn eval, void* ctx);
 /* root statistics after simulate */
 int orc_mcts_root_stats(orc_mcts* m, const orc_state* root, uint32_t* n43, float* q43, float* p43, uint32_t* sumN);
