@@ -70,6 +70,14 @@ def test_create_destroy_does_not_leak_device_memory():
         eng.init_random(i)
         eng.selfplay_start(i)
         eng.selfplay_run(20)
+        rec = eng.drain()
+        if i % 3 == 0:   # the lazily created parts too: second tree + leaf lists of the two-net arena, optimiser context
+            eng.arena_set_opponent(eng)
+            eng.arena_start(P.PLAYER_ALPHAZERO, P.PLAYER_ALPHAZERO_B, 4, 0, True, 5)
+            eng.arena_run(30)
+            eng.arena_set_opponent(None)
+            if len(rec) >= 32:
+                eng.train_batch(rec[:32])
         eng.close()
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
