@@ -139,6 +139,12 @@ def test_steps_are_reproducible_and_adam_state_persists():
             w, m, v = tf_adam(w, g, m, v, t + 1, k)
             w[k == 0] = mov[k == 0]
             assert np.abs(mov[k > 0] - w[k > 0]).max() <= 5e-7
+        # a different batch size rebuilds the activation buffers but keeps the Adam moments and step count
+        eng.train_batch(rec[:bs // 2])
+        g = eng.train_grads()
+        mov = eng.get_weights()
+        w, m, v = tf_adam(w, g, m, v, 4, k)
+        assert np.abs(mov[k > 0] - w[k > 0]).max() <= 5e-7
         outs.append(eng.get_weights())
         eng.close()
     assert (outs[0].view(np.uint32) == outs[1].view(np.uint32)).all()   # atomic-free reductions: bit-reproducible
