@@ -122,14 +122,29 @@ def main():
     c0 = eng.counters()
     barrier()
     t0 = time.perf_counter()
-    eng.selfplay_run(a.steps)          # EXACTLY K passes (synchronises at the end)
+    # EXACTLY K passes, issued in 10 slices so that a median rate can be reported next to the mean; a slice
+    # boundary is one counter read-back (a stream sync of a few microseconds)
+    chunk_rates, profs, done, prev_sims, prev_t = [], [], 0, c0["simulations"], t0
+    for i in range(10):
+        n = (a.steps * (i + 1)) // 10 - done
+        if n <= 0:
+            continue
+        eng.selfplay_run(n)
+        done += n
+        now, cs = time.perf_counter(), eng.counters()["simulations"]
+        chunk_rates.append((cs - prev_sims) / max(now - prev_t, 1e-9))
+        profs.append(eng.profile_last_run())
+        prev_sims, prev_t = cs, now
     ptr, nrec = eng.samples_device_view()
     recs = shard.device_records_to_torch(ptr, nrec, dev)
     allrecs = shard.gather_records(recs.to(cdev), dist if world > 1 else None)   # the path's one exchange step
     barrier()
     dt = time.perf_counter() - t0
     c1 = eng.counters()
-    prof = eng.profile_last_run()
+    # HIP-event timings of the kernels (on the engine's stream), launch-weighted over the slices of the timed region
+    nl = max(1, sum(p_["launches"] for p_ in profs))
+    prof = {"net_ms": sum(p_["net_ms"] * p_["launches"] for p_ in profs) / nl,
+            "tree_ms": sum(p_["tree_ms"] * p_["launches"] for p_ in profs) / nl, "launches": sum(p_["launches"] for p_ in profs)}
 
     delta = {k: c1[k] - c0[k] for k in c1}
     tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -174,6 +189,7 @@ def main():
                                    f"THREADS_PER_MCTS {a.threads}, {a.blocks}-block 256-filter random-init net (BASELINE configs[1])",
                        "games_per_gpu": a.games, "sims_per_move": a.sims, "mcts_threads": a.threads, "blocks": a.blocks,
                        "parallelism": f"games sharded x{world}, no data-path collective; 1 all_gather of records"},
+            "simulations_per_s_p50_rank0": sorted(chunk_rates)[len(chunk_rates) // 2] if chunk_rates else None,
             "self_play_games_per_s": games_rate["games_per_s"] if games_rate else games / dt,
             "self_play_games_window": games_rate, "decisions_per_s": decisions / dt,
             "net_evals_per_s": evals / dt, "mean_depth": levels / max(1, sims),
