@@ -13,7 +13,7 @@ FM = T.data_field_mask()
 
 def test_bulk_random_games_bit_exact(orc):
     steps = 0
-    for seed in range(1000, 1400):
+    for seed in range(1000, 11000):   # SURVEY §7 gate 2: >= 10 k seeded games, every state / mask / move / outcome
         g = T.ref_random_game(seed)
         h = T.orc_random_game(seed)
         assert len(g["moves"]) == len(h["moves"]), seed
@@ -22,7 +22,7 @@ def test_bulk_random_games_bit_exact(orc):
         assert (g["states"][:, FM] == h["states"][:, FM]).all(), seed
         assert g["status"] == h["status"] and (g["final"][FM] == h["final"][FM]).all()
         steps += len(g["moves"])
-    assert steps > 100000
+    assert steps > 3000000
 
 
 @pytest.mark.parametrize("rules", [dict(allow_yield=0), dict(limit_reinforcement=0), dict(limit_attack=1),
