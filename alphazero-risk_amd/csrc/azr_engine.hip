@@ -830,6 +830,7 @@ extern "C" int azr_engine_create(const azr_settings* s, azr_engine** out)
 {
     if (!s || !out || s->games <= 0 || s->blocks <= 0 || s->mcts_simulations < 0) return AZR_E_INVALID_ARGUMENT;
     if (s->mcts_threads < 1 || s->mcts_threads > MAX_THREADS) return AZR_E_INVALID_ARGUMENT;
+    if (s->mcts_simulations > 0 && s->mcts_simulations < s->mcts_threads) return AZR_E_INVALID_ARGUMENT;  // count = S - S % T would be 0
     azr_engine* h = new (std::nothrow) azr_engine();
     if (!h) return AZR_E_HIP;
     h->cfg = *s;

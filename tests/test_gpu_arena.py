@@ -43,6 +43,25 @@ def test_script_and_random_players_arena_bit_exact(orc, kinds, mirror):
     eng.close()
 
 
+def test_ten_thousand_games_through_the_device_rules_bit_exact(orc):
+    """volume check of the device rules engine (SURVEY §7 gate 4 at the size of gate 2): 1024 slots x 10 games of
+    RandomPlayer vs ScriptPlayer, unmirrored (every game a fresh deal): statuses, round counts, final states per game"""
+    P = pkg()
+    G, per_slot, base = 1024, 10, 900000
+    eng = P.Engine(G, blocks=1, sims=1, dtype=P.NET_F32, node_capacity=64)
+    res, (n, st, rd, fin) = run_arena(eng, P.PLAYER_RANDOM, P.PLAYER_SCRIPT, 10 ** 7, per_slot, False, base)
+    assert (n == per_slot).all() and eng.counters()["errors"] == 0 and res["count"] == G * per_slot
+    tot = np.zeros(6, np.int64)
+    for g in range(G):
+        r6, ost, ord_, ofin, _ = T.orc_play_games(P.PLAYER_RANDOM, P.PLAYER_SCRIPT, per_slot, False, base + g)
+        assert (st[g, :per_slot] == ost).all() and (rd[g, :per_slot] == ord_).all(), g
+        assert (fin[g, :per_slot][:, FM] == ofin[:, FM]).all(), g
+        tot += np.array(r6)
+    assert [res["count"], res["draw"], res["win"][0], res["win_and_started"][0], res["win"][1],
+            res["win_and_started"][1]] == list(tot)
+    eng.close()
+
+
 def test_counter_semantics_pairs_and_quota():
     """Counter::hasNext(2) (game.cpp:14-26): games are taken in pairs from a shared counter; an odd quota leaves the
     last game unplayed"""

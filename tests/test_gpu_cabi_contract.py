@@ -61,6 +61,14 @@ def test_misuse_returns_error_codes(tmp_path):
     eng.close()
 
 
+def test_thread_count_is_validated():
+    P = pkg()
+    for kw in (dict(threads=0), dict(threads=9), dict(threads=4, sims=3)):
+        with pytest.raises(P.AzrError) as e:
+            P.Engine(4, blocks=1, **({"sims": 8} | kw))
+        assert e.value.code == 1   # AZR_E_INVALID_ARGUMENT
+
+
 def test_create_destroy_does_not_leak_device_memory():
     P = pkg()
     torch.cuda.synchronize()
