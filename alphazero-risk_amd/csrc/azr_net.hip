@@ -423,14 +423,17 @@ extern "C" int azr_nn_get_weights(azr_engine* h, float* flat, size_t count)
 extern "C" int azr_nn_save(azr_engine* h, const char* path)
 {
     if (!h) return AZR_E_BAD_HANDLE;
-    FILE* f = fopen(path, "wb");
-    if (!f) { h->err = std::string("cannot open ") + path; return AZR_E_IO; }
+    // written next to the target and renamed into place: a concurrent reader never sees a partial checkpoint
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) { h->err = std::string("cannot open ") + tmp; return AZR_E_IO; }
     const uint32_t ver = 1, blocks = (uint32_t)h->net.blocks;
     const uint64_t count = h->flat.size();
     bool ok = fwrite("AZRW", 1, 4, f) == 4 && fwrite(&ver, 4, 1, f) == 1 && fwrite(&blocks, 4, 1, f) == 1 &&
               fwrite(&count, 8, 1, f) == 1 && fwrite(h->flat.data(), 4, count, f) == count;
-    fclose(f);
-    if (!ok) { h->err = "short write"; return AZR_E_IO; }
+    ok = fclose(f) == 0 && ok;
+    if (!ok) { remove(tmp.c_str()); h->err = "short write"; return AZR_E_IO; }
+    if (rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); h->err = std::string("cannot rename to ") + path; return AZR_E_IO; }
     return AZR_OK;
 }
 

@@ -264,31 +264,6 @@ __global__ __launch_bounds__(256) void t_split(const float* __restrict__ x, size
     reinterpret_cast<uint2*>(p1)[i] = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
     if (NP == 3) reinterpret_cast<uint2*>(p2)[i] = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
 }
-// the 2B tower kernels of the flat vector -> contiguous part arrays [2B][9*256*256]
-template <int NP>
-__global__ __launch_bounds__(256) void t_split_w(const float* __restrict__ flat, uint16_t* __restrict__ p0, uint16_t* __restrict__ p1,
-                                                 uint16_t* __restrict__ p2)
-{
-    const size_t wn4 = (size_t)9 * NF * NF / 4;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index inside the layer
-    if (i >= wn4) return;
-    const int l = blockIdx.y;
-    const float4 v4 = reinterpret_cast<const float4*>(flat + OFF_BLOCK0 + (size_t)l * LAYER)[i];
-    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
-    uint32_t h[4], m[4], lo[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        h[j] = bf_rne_bits(v[j]);
-        const float r1 = v[j] - __uint_as_float(h[j] << 16);
-        m[j] = bf_rne_bits(r1);
-        lo[j] = bf_rne_bits(r1 - __uint_as_float(m[j] << 16));
-    }
-    const size_t o = (size_t)l * wn4 + i;
-    reinterpret_cast<uint2*>(p0)[o] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-    reinterpret_cast<uint2*>(p1)[o] = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
-    if (NP == 3) reinterpret_cast<uint2*>(p2)[o] = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
-}
-
 // k-contiguous operand (storage [mn][k]): T rows x 32 k per tile; T / 64 16-byte loads (8 bf16) per thread and part
 template <int T, int MODE, int NP>
 __device__ __forceinline__ void sb_load_kc(const Parts& P, int ld, int mn0, int k0, int MN, int Kend, int t, uint4 (&r)[NP][T / 64])
@@ -408,21 +383,21 @@ __global__ __launch_bounds__(256) void t_gemm_sb(Parts A, int lda, Parts B, int 
         for (int q = 0; q < NP; q++)
 #pragma unroll
             for (int j = 0; j < 4; j++) b[q][j] = *reinterpret_cast<const s16x8*>(Bs + q * SB + (wn * 64 + j * 16) * KP3 + fo);
+        s16x8 a[NP][MI];
 #pragma unroll
-        for (int i = 0; i < MI; i++) {
-            s16x8 a[NP];
+        for (int q = 0; q < NP; q++)
 #pragma unroll
-            for (int q = 0; q < NP; q++) a[q] = *reinterpret_cast<const s16x8*>(As + q * SA + (wm * (BM / 2) + i * 16) * KP3 + fo);
-#define SB_MFMA(qa, qb) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[qa]), __builtin_bit_cast(bf16x8, b[qb][j]), acc[i][j], 0, 0, 0)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {  // smallest terms first
-                if constexpr (NP == 3) { SB_MFMA(2, 0); SB_MFMA(0, 2); SB_MFMA(1, 1); }
-                SB_MFMA(1, 0);
-                SB_MFMA(0, 1);
-                SB_MFMA(0, 0);
-            }
-#undef SB_MFMA
-        }
+            for (int i = 0; i < MI; i++) a[q][i] = *reinterpret_cast<const s16x8*>(As + q * SA + (wm * (BM / 2) + i * 16) * KP3 + fo);
+        // part pairs outermost (smallest terms first): back-to-back MFMAs then write DIFFERENT accumulators — a chain of
+        // dependent MFMAs on one accumulator would leave the matrix pipe idle for most of each instruction's latency
+#define SB_PASS(qa, qb)                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < MI; i++) _Pragma("unroll") for (int j = 0; j < 4; j++)                          \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[qa][i]), __builtin_bit_cast(bf16x8, b[qb][j]), acc[i][j], 0, 0, 0)
+        if constexpr (NP == 3) { SB_PASS(2, 0); SB_PASS(0, 2); SB_PASS(1, 1); }
+        SB_PASS(1, 0);
+        SB_PASS(0, 1);
+        SB_PASS(0, 0);
+#undef SB_PASS
     }
     float* Cz = C + (size_t)blockIdx.z * strideCz;
 #pragma unroll
@@ -434,6 +409,123 @@ __global__ __launch_bounds__(256) void t_gemm_sb(Parts A, int lda, Parts B, int 
                 const int row = m0 + wm * (BM / 2) + i * 16 + 4 * (lane >> 4) + e;
                 const int col = n0 + wn * 64 + j * 16 + (lane & 15);
                 if (row < M && col < N) Cz[(size_t)row * ldc + col] = acc[i][j][e];
+            }
+}
+
+// =====================================================================================================================
+// Conv GEMMs whose B operand is the layer's kernel (forward, backward-data): N = 256, K = 2304.  The measured limit of
+// t_gemm_sb on these shapes is LDS traffic, two thirds of it the weight tile.  Here the weights never touch LDS: t_pack_w
+// writes their bf16 parts once per step in MFMA-fragment order ([k-tile][n-tile][lane][8]) and every wave loads the
+// fragments of ITS 32 columns straight from global memory (1 KB coalesced per fragment, register double buffer).  Block =
+// 64 rows x 128 columns, 4 waves side by side (64 x 32 each); only the activation tile goes through LDS.
+//   VIEW 0: forward        B[k = tap*256+ci][n = co] = W[tap][ci][co]
+//   VIEW 1: backward-data  B[k = tap*256+co][n = ci] = W[tap][ci][co]
+// =====================================================================================================================
+constexpr size_t WPACK = (size_t)KC * NF;  // elements per layer, part and view
+
+template <int NP>
+__global__ __launch_bounds__(256) void t_pack_w(const float* __restrict__ flat, int view, uint16_t* __restrict__ p0, uint16_t* __restrict__ p1,
+                                                uint16_t* __restrict__ p2)
+{
+    // one thread = one lane's 8 values of one fragment: index = ((kt * 16 + nt) * 64 + lane)
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= WPACK / 8) return;
+    const int l = blockIdx.y;
+    const float* W = flat + OFF_BLOCK0 + (size_t)l * LAYER;
+    const int lane = (int)(i & 63), nt = (int)((i >> 6) & 15), kt = (int)(i >> 10);
+    const int n = nt * 16 + (lane & 15), k0 = kt * 32 + (lane >> 4) * 8, tap = k0 >> 8, c0 = k0 & 255;
+    uint32_t h[8], m[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float v = view == 0 ? W[((size_t)tap * NF + (c0 + j)) * NF + n]    // ci = c0 + j, co = n
+                                  : W[((size_t)tap * NF + n) * NF + (c0 + j)];   // ci = n, co = c0 + j
+        h[j] = bf_rne_bits(v);
+        const float r1 = v - __uint_as_float(h[j] << 16);
+        m[j] = bf_rne_bits(r1);
+        lo[j] = bf_rne_bits(r1 - __uint_as_float(m[j] << 16));
+    }
+    const size_t o = (size_t)l * (WPACK / 8) + i;
+    reinterpret_cast<uint4*>(p0)[o] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    reinterpret_cast<uint4*>(p1)[o] = make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
+    if (NP == 3) reinterpret_cast<uint4*>(p2)[o] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+}
+
+// C[M][256] = im2col(A) x B.  AMODE 1 (forward taps) / 2 (negated taps); A = bf16 parts of an activation [M][256];
+// Bp = packed parts of this layer's kernel in the matching view.  One block iteration covers KS MFMA k-steps (KS * 32 of
+// K) between two barriers (KS = 2 measured within 2 % of KS = 1, which is used).
+template <int AMODE, int NP, int KS>
+__global__ __launch_bounds__(256) void t_conv_sb(Parts A, Parts Bp, float* __restrict__ C, int M)
+{
+    constexpr int BM = 64, LDK = KS * K3 + 8, SA = BM * LDK, KT = KC / (KS * K3);
+    __shared__ __attribute__((aligned(16))) uint16_t As[NP * SA];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int m0 = blockIdx.y * BM, nt0 = blockIdx.x * 8 + wave * 2;  // this wave's two 16-column tiles
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 ra[KS][NP][1];
+    uint4 rb[KS][NP][2];
+    auto loadA = [&](int kt) {
+#pragma unroll
+        for (int s2 = 0; s2 < KS; s2++) sb_load_kc<BM, AMODE, NP>(A, 0, m0, (kt * KS + s2) * K3, M, KC, t, ra[s2]);
+    };
+    auto loadB = [&](int kt) {
+#pragma unroll
+        for (int s2 = 0; s2 < KS; s2++)
+#pragma unroll
+            for (int q = 0; q < NP; q++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    rb[s2][q][j] = reinterpret_cast<const uint4*>(Bp.p[q])[((size_t)(kt * KS + s2) * 16 + nt0 + j) * 64 + lane];
+    };
+    loadA(0);
+    loadB(0);
+    const int so = (t >> 2) * LDK + (t & 3) * 8;                 // this thread's 8 k-values of a 64 x 32 sub-tile
+    const int fo = (lane & 15) * LDK + (lane >> 4) * 8;          // this lane's fragment offset inside a 16-row tile
+    for (int kt = 0; kt < KT; kt++) {
+        __syncthreads();
+#pragma unroll
+        for (int s2 = 0; s2 < KS; s2++)
+#pragma unroll
+            for (int q = 0; q < NP; q++) *reinterpret_cast<uint4*>(As + q * SA + so + s2 * K3) = ra[s2][q][0];
+        __syncthreads();
+        uint4 b[KS][NP][2];   // this iteration's weight fragments; the registers are refilled for the next one right away
+#pragma unroll
+        for (int s2 = 0; s2 < KS; s2++)
+#pragma unroll
+            for (int q = 0; q < NP; q++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) b[s2][q][j] = rb[s2][q][j];
+        if (kt + 1 < KT) { loadA(kt + 1); loadB(kt + 1); }
+#pragma unroll
+        for (int s2 = 0; s2 < KS; s2++) {
+            s16x8 a[NP][4];
+#pragma unroll
+            for (int q = 0; q < NP; q++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) a[q][i] = *reinterpret_cast<const s16x8*>(As + q * SA + (i * 16) * LDK + s2 * K3 + fo);
+            // part pairs outermost (smallest terms first): consecutive MFMAs write different accumulators (see t_gemm_sb)
+#define CV_PASS(qa, qb)                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; i++) _Pragma("unroll") for (int j = 0; j < 2; j++)                           \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[qa][i]), __builtin_bit_cast(bf16x8, b[s2][qb][j]), acc[i][j], 0, 0, 0)
+            if constexpr (NP == 3) { CV_PASS(2, 0); CV_PASS(0, 2); CV_PASS(1, 1); }
+            CV_PASS(1, 0);
+            CV_PASS(0, 1);
+            CV_PASS(0, 0);
+#undef CV_PASS
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int row = m0 + i * 16 + 4 * (lane >> 4) + e;
+                const int col = (nt0 + j) * 16 + (lane & 15);
+                if (row < M) C[(size_t)row * NF + col] = acc[i][j][e];
             }
 }
 
@@ -1077,7 +1169,8 @@ struct TrainCtx {
     float* sums = nullptr;                   // [2][256]
     double* part = nullptr;                  // [R][2*NG][256]
     float* wpart = nullptr;                  // split-K partials [nz][KC][256]
-    uint16_t *ap[3] = {nullptr, nullptr, nullptr}, *dyp[2] = {nullptr, nullptr}, *wp[3] = {nullptr, nullptr, nullptr};  // bf16 parts
+    uint16_t *ap[3] = {nullptr, nullptr, nullptr}, *dyp[2] = {nullptr, nullptr};          // bf16 parts of activations / gradients
+    uint16_t *wpf[3] = {nullptr, nullptr, nullptr}, *wpb[2] = {nullptr, nullptr};        // packed kernels: forward / backward-data view
     float *pv0 = nullptr, *dpv = nullptr, *hstat = nullptr, *fpi = nullptr, *fv = nullptr, *h1 = nullptr, *vout = nullptr,
           *prob = nullptr, *lossb = nullptr, *hpart = nullptr, *cpart = nullptr, *loss = nullptr;
     int* cur = nullptr;    // device: {minibatch offset in perm, Adam step count}
@@ -1158,7 +1251,8 @@ int ctx_ensure(azr_engine* h, int BS)
     TRY(dalloc(h, c, &c->sums, (size_t)2 * NF));
     TRY(dalloc(h, c, &c->part, (size_t)c->R * 2 * NG * NF));
     TRY(dalloc(h, c, &c->wpart, (size_t)c->nz * KC * NF));
-    for (int q = 0; q < 3; q++) { TRY(dalloc(h, c, &c->ap[q], act)); TRY(dalloc(h, c, &c->wp[q], (size_t)2 * B * KC * NF)); }
+    for (int q = 0; q < 3; q++) { TRY(dalloc(h, c, &c->ap[q], act)); TRY(dalloc(h, c, &c->wpf[q], (size_t)2 * B * KC * NF)); }
+    for (int q = 0; q < 2; q++) TRY(dalloc(h, c, &c->wpb[q], (size_t)2 * B * KC * NF));
     for (int q = 0; q < 2; q++) TRY(dalloc(h, c, &c->dyp[q], act));
     TRY(dalloc(h, c, &c->pv0, M * 4)); TRY(dalloc(h, c, &c->dpv, M * 4)); TRY(dalloc(h, c, &c->hstat, (size_t)8));
     TRY(dalloc(h, c, &c->fpi, (size_t)BS * 84)); TRY(dalloc(h, c, &c->fv, (size_t)BS * 42)); TRY(dalloc(h, c, &c->h1, (size_t)BS * 256));
@@ -1238,11 +1332,13 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     auto Al = [&](int l) { return c->A + act * l; };
     const unsigned g4 = (unsigned)((act / 4 + 255) / 256);
     const bool sb = g_gemm_bf16x3 && M % K3 == 0;  // split-bf16 conv GEMMs (the stem, K = 144, stays on the fp32 MFMA)
-    auto Wp = [&](int l) {
-        const size_t o = (size_t)(l - 1) * KC * NF;
-        return Parts{{c->wp[0] + o, c->wp[1] + o, c->wp[2] + o}};
-    };
-    if (sb) hipLaunchKernelGGL((t_split_w<3>), dim3((unsigned)((wn_ / 4 + 255) / 256), 2 * B), dim3(256), 0, st, w, c->wp[0], c->wp[1], c->wp[2]);
+    auto Wpf = [&](int l) { const size_t o = (size_t)(l - 1) * KC * NF; return Parts{{c->wpf[0] + o, c->wpf[1] + o, c->wpf[2] + o}}; };
+    auto Wpb = [&](int l) { const size_t o = (size_t)(l - 1) * KC * NF; return Parts{{c->wpb[0] + o, c->wpb[1] + o, nullptr}}; };
+    if (sb) {
+        const dim3 pg((unsigned)((wn_ / 8 + 255) / 256), 2 * B);
+        hipLaunchKernelGGL((t_pack_w<3>), pg, dim3(256), 0, st, w, 0, c->wpf[0], c->wpf[1], c->wpf[2]);
+        hipLaunchKernelGGL((t_pack_w<2>), pg, dim3(256), 0, st, w, 1, c->wpb[0], c->wpb[1], (uint16_t*)nullptr);
+    }
 
     // ---------------- forward, training mode
     hipLaunchKernelGGL(t_planes, grid1((size_t)M * SIN, 256), dim3(256), 0, st, c->in88, M, c->X0);
@@ -1259,7 +1355,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         float* bn = Wl(l) + (size_t)9 * NF * NF;
         const float* S = (l % 2 == 0) ? Al(l - 2) : nullptr;  // second conv of a block adds the block input
         if (sb) {  // conv = implicit im2col x W, 6-pass split bf16 (fp32-exact products)
-            gemm_sb<false, false, 64, 1, 0, 3>(st, Parts{{c->ap[0], c->ap[1], c->ap[2]}}, KC, Wp(l), NF, Yl(l), NF, M, NF, KC);
+            hipLaunchKernelGGL((t_conv_sb<1, 3, 1>), dim3(2, (M + 63) / 64), dim3(256), 0, st, Parts{{c->ap[0], c->ap[1], c->ap[2]}}, Wpf(l), Yl(l), M);
         } else gemm<false, false, 64, 1, 0>(st, Al(l - 1), KC, Wl(l), NF, Yl(l), NF, M, NF, KC);
         hipLaunchKernelGGL((t_bn_stats<false>), dim3(R), dim3(1024), 0, st, Yl(l), M, c->part);
         hipLaunchKernelGGL((t_bn_finalize<false>), dim3(8), dim3(1024), 0, st, c->part, R, (double)M, c->mean + l * NF, c->istd + l * NF, bn);
@@ -1299,7 +1395,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, c->nz, wn, Gl(l));
         // d(input) = transposed conv of dY with W: the same implicit GEMM with negated taps and W read as [tap][co] x [ci]
         float* dIn = second ? c->DT : c->G;
-        if (sb) gemm_sb<false, true, 64, 2, 3, 2>(st, Parts{{c->dyp[0], c->dyp[1], nullptr}}, KC, Wp(l), NF, dIn, NF, M, NF, KC);
+        if (sb) hipLaunchKernelGGL((t_conv_sb<2, 2, 1>), dim3(2, (M + 63) / 64), dim3(256), 0, st, Parts{{c->dyp[0], c->dyp[1], nullptr}}, Wpb(l), dIn, M);
         else gemm<false, true, 64, 2, 3>(st, c->dY, KC, Wl(l), NF, dIn, NF, M, NF, KC);
         if (!second) hipLaunchKernelGGL(t_add, dim3(g4), dim3(256), 0, st, dIn, c->DS, act / 4);  // + shortcut gradient
     }

@@ -166,15 +166,14 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
     gen = P.Engine(a.gpu_games, blocks=a.blocks, sims=a.mcts, dtype=dtype, device=a.device, threads=t)
     new = P.Engine(a.gpu_games, blocks=a.blocks, sims=a.mcts, dtype=dtype, device=a.device, threads=t)
     latest, best = "checkpoints/latest-checkpoint.bin", "checkpoints/best-checkpoint.bin"
-    for e in (new, gen):  # loadCheckpoint: missing => init + save (alphazero_nn.cpp:197-202)
-        if os.path.exists(latest):
-            e.load(latest)
-        else:
-            e.init_random(20260002)
-            if rank == 0:
-                e.save(latest)
+    # loadCheckpoint: missing => init + save (alphazero_nn.cpp:197-202).  Rank 0 creates the file before anybody reads it.
+    if rank == 0 and not os.path.exists(latest):
+        new.init_random(20260002)
+        new.save(latest)
     if dist is not None:
         dist.barrier()
+    for e in (new, gen):
+        e.load(latest)
     trainer = None
     if getattr(a, "trainer", "native") == "torch":
         trainer = train_mod.Trainer(a.blocks, new.get_weights(), device=f"cuda:{a.device}", batch_size=a.bs, seed=a.seed)
