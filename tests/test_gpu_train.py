@@ -83,8 +83,14 @@ def tf_adam(w, g, m, v, t, k):
     return np.where(tr, w2, w), np.where(tr, m2, m), np.where(tr, v2, v)
 
 
-@pytest.mark.parametrize("blocks,bs", [(1, 16), (2, 64)])
-def test_step_matches_torch_graph(blocks, bs):
+@pytest.mark.parametrize("blocks,bs,gemm", [(1, 16, "split"), (2, 64, "split"), (2, 64, "f32"), (1, 10, "split")])
+def test_step_matches_torch_graph(blocks, bs, gemm, monkeypatch):
+    """gemm = "split": the split-bf16 conv GEMMs (default); "f32": the fp32-MFMA GEMMs (AZR_TRAIN_GEMM=f32); batch 10
+    (42 * 10 rows, not a multiple of the 32-deep k-tile) takes the fp32 kernels by itself"""
+    if gemm == "f32":
+        monkeypatch.setenv("AZR_TRAIN_GEMM", "f32")
+    else:
+        monkeypatch.delenv("AZR_TRAIN_GEMM", raising=False)
     P = pkg()
     flat = T.make_net_flat(blocks, seed=11, perturb_bn=True)
     rec = records(bs, seed=blocks)
