@@ -39,7 +39,7 @@ PLAYER_ALPHAZERO, PLAYER_SCRIPT, PLAYER_RANDOM, PLAYER_ALPHAZERO_B = 0, 1, 2, 3
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("simulations", "evaluations", "levels", "decisions", "games_finished",
-                                          "samples", "nodes_dropped", "errors")]
+                                          "samples", "nodes_dropped", "errors", "records_dropped")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -63,8 +63,8 @@ EXPORTS = [
     "azr_engine_valid_moves", "azr_engine_make_moves", "azr_engine_status", "azr_engine_encode",
     "azr_nn_param_count", "azr_nn_init_random", "azr_nn_set_weights", "azr_nn_get_weights", "azr_nn_load", "azr_nn_save",
     "azr_nn_predict", "azr_nn_train", "azr_nn_train_batch", "azr_nn_train_grads", "azr_nn_train_reset", "azr_mcts_clear", "azr_mcts_trim", "azr_mcts_simulate", "azr_mcts_begin", "azr_mcts_leaves",
-    "azr_mcts_apply", "azr_mcts_root_stats", "azr_mcts_policy", "azr_mcts_pick", "azr_selfplay_start", "azr_selfplay_run",
-    "azr_selfplay_counters", "azr_samples_drain", "azr_samples_device_view", "azr_profile_last_run",
+    "azr_mcts_apply", "azr_mcts_root_stats", "azr_mcts_policy", "azr_mcts_pick", "azr_selfplay_start", "azr_selfplay_start_games",
+    "azr_selfplay_run", "azr_selfplay_counters", "azr_samples_drain", "azr_samples_device_view", "azr_samples_copy_device", "azr_profile_last_run",
     "azr_device_synchronize", "azr_arena_start", "azr_arena_run", "azr_arena_results", "azr_arena_log",
     "azr_arena_set_opponent_net", "azr_arena_collect_samples",
 ]
@@ -99,6 +99,8 @@ def load_library():
         L.azr_nn_train_grads.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.azr_nn_train_reset.argtypes = [C.c_void_p]
         L.azr_selfplay_start.argtypes = [C.c_void_p, C.c_uint32]
+        L.azr_selfplay_start_games.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+        L.azr_samples_copy_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.azr_selfplay_run.argtypes = [C.c_void_p, C.c_int]
         L.azr_samples_drain.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.azr_samples_device_view.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -152,12 +154,9 @@ class Engine:
         self.blocks = blocks
         self.h = C.c_void_p()
         rc = self.L.azr_engine_create(C.byref(s), C.byref(self.h))
-        if rc:
-            msg = self.L.azr_last_error(self.h).decode() if self.h else "create failed"
-            if self.h:
-                self.L.azr_engine_destroy(self.h)
-                self.h = None
-            raise AzrError(rc, msg)
+        if rc:  # *out is NULL on failure; the reason is kept per thread
+            self.h = None
+            raise AzrError(rc, self.L.azr_last_error(None).decode())
 
     def close(self):
         if getattr(self, "h", None):
@@ -325,6 +324,10 @@ class Engine:
     def selfplay_start(self, base_seed=20260001):
         self._chk(self.L.azr_selfplay_start(self.h, base_seed))
 
+    def selfplay_start_games(self, base_seed, games):
+        """exactly `games` games (seeds base_seed .. base_seed + games - 1), each played to its end"""
+        self._chk(self.L.azr_selfplay_start_games(self.h, base_seed, games))
+
     def selfplay_run(self, passes):
         self._chk(self.L.azr_selfplay_run(self.h, passes))
 
@@ -334,12 +337,22 @@ class Engine:
         return c.as_dict()
 
     def drain(self, cap=None):
+        """the first `cap` buffered records (default: all); what does not fit stays buffered"""
         if cap is None:
             cap = max(1, self.samples_device_view()[1])
         buf = np.empty((cap, RECORD_BYTES), np.uint8)
         n = C.c_size_t(0)
         self._chk(self.L.azr_samples_drain(self.h, _p(buf), cap, C.byref(n)))
         return buf[:n.value].copy()
+
+    def discard_samples(self):
+        self._chk(self.L.azr_samples_drain(self.h, None, 0, None))
+
+    def samples_copy_device(self, dst_ptr, cap):
+        """copy up to `cap` buffered records to device memory at dst_ptr (engine stream); returns the count"""
+        n = C.c_size_t(0)
+        self._chk(self.L.azr_samples_copy_device(self.h, C.c_void_p(dst_ptr), cap, C.byref(n)))
+        return n.value
 
     def samples_device_view(self):
         ptr = C.c_void_p()

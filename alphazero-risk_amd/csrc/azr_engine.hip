@@ -15,6 +15,7 @@ using namespace azr;
     do {                                                                                        \
         hipError_t e__ = (call);                                                                \
         if (e__ != hipSuccess) {                                                                \
+            (void)hipGetLastError(); /* the runtime's last-error slot is sticky: clear it */        \
             (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
             return AZR_E_HIP;                                                                   \
         }                                                                                       \
@@ -436,11 +437,21 @@ __device__ __forceinline__ uint32_t root_node(const Tree& t, const WS& root, uin
     return ridx;
 }
 
-// the slot's next self-play game: seeds base + g, base + G + g, ...
+// the slot's next self-play game.  Unlimited mode: seeds base + g, base + G + g, ...  Quota mode (azr_selfplay_start_games,
+// Counter::hasNext of alphazero_trainer.cpp:83): the next game index is a ticket from one atomic counter — exactly
+// sp_quota games are started, seeds base .. base + sp_quota - 1, each game a function of its seed alone; a slot that
+// draws no ticket goes idle (mode 0).
 __device__ __forceinline__ void selfplay_next_game(const Dev& E, int g, const Tree& t, Ctl& c, WS& root)
 {
     c.game_no++;
     c.seed = E.base_seed + c.game_no * (uint32_t)E.G + (uint32_t)g;
+    if (E.sp_quota) {
+        unsigned long long ticket = 0;
+        if (lane_id() == 0) ticket = atomicAdd(E.sp_started, 1ull);
+        ticket = rfl64(ticket);
+        if (ticket >= E.sp_quota) { c.mode = 0; c.pending = 0; c.nsamples = 0; return; }
+        c.seed = E.base_seed + (uint32_t)ticket;
+    }
     ws_blank(root);
     root.rng = rng_seed(c.seed);
     new_game(root);
@@ -504,6 +515,7 @@ __global__ __launch_bounds__(64) void k_tree_step(Dev E)
                 selfplay_next_game(E, g, t, c, root);
             }
             root_dirty = true;
+            if (c.mode == 0) break;  // quota exhausted: the slot idles
             tree_trim(t, c);
             c.sims_done = 0; c.sims_started = 0;
         }
@@ -515,8 +527,9 @@ __global__ __launch_bounds__(64) void k_tree_step(Dev E)
             c.error = err;
             if (SELFPLAY) {  // abandon the game (the reference would have thrown): restart the slot
                 selfplay_next_game(E, g, t, c, root);
-                tree_trim(t, c);
                 root_dirty = true;
+                if (c.mode == 0) break;
+                tree_trim(t, c);
                 continue;
             }
             c.search_done = 1;
@@ -787,6 +800,7 @@ __global__ __launch_bounds__(64) void k_selfplay_start(Dev E)
     c.mode = 2; c.sims_done = 0; c.sims_started = 0; c.pending = 0; c.search_done = 0; c.error = 0;
     c.game_no = 0; c.nsamples = 0; c.decisions = 0; c.status = ST_NOT_ENDED;
     c.seed = E.base_seed + (uint32_t)g;
+    if (E.sp_quota && (unsigned long long)g >= E.sp_quota) c.mode = 0;  // fewer games asked for than slots
     WS s;
     ws_blank(s);
     s.rng = rng_seed(c.seed);
@@ -826,28 +840,52 @@ extern "C" void azr_default_settings(azr_settings* s)
 template <typename T>
 static hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, n * sizeof(T)); }
 
+static thread_local std::string g_create_err;   // why the last azr_engine_create of this thread failed
+static int engine_init(azr_engine* h, const azr_settings* s);
+
 extern "C" int azr_engine_create(const azr_settings* s, azr_engine** out)
 {
     if (!s || !out || s->games <= 0 || s->blocks <= 0 || s->mcts_simulations < 0) return AZR_E_INVALID_ARGUMENT;
     if (s->mcts_threads < 1 || s->mcts_threads > MAX_THREADS) return AZR_E_INVALID_ARGUMENT;
     if (s->mcts_simulations > 0 && s->mcts_simulations < s->mcts_threads) return AZR_E_INVALID_ARGUMENT;  // count = S - S % T would be 0
+    *out = nullptr;
+    // node indices are 16-bit (azr_tree.hpp): a pool above 65 534 nodes per game cannot be addressed.  Rejected, not
+    // clamped: a silently smaller pool would change which expansions are dropped.
+    const long long want_nodes = s->node_capacity > 0 ? (long long)s->node_capacity : 16ll * (s->mcts_simulations + 1);
+    if (want_nodes > 65534) {
+        g_create_err = "azr_engine_create: node pool of " + std::to_string(want_nodes) + " nodes per game (node_capacity, or the default "
+                       "16 * (mcts_simulations + 1)) exceeds the 65534 a 16-bit node index addresses; pass node_capacity <= 65534";
+        return AZR_E_INVALID_ARGUMENT;
+    }
     azr_engine* h = new (std::nothrow) azr_engine();
-    if (!h) return AZR_E_HIP;
+    if (!h) { g_create_err = "azr_engine_create: out of host memory"; return AZR_E_HIP; }
+    const int rc_create = engine_init(h, s);
+    if (rc_create) {  // nothing half-built is handed out: free what was allocated, keep the message for azr_last_error(NULL)
+        g_create_err = h->err;
+        azr_engine_destroy(h);
+        return rc_create;
+    }
+    *out = h;
+    return AZR_OK;
+}
+
+static int engine_init(azr_engine* h, const azr_settings* s)
+{
     h->cfg = *s;
     h->mode = 0;
     h->weights_set = false;
     h->prof_net_ms = h->prof_tree_ms = h->prof_tower_ms = 0;
     h->prof_launches = 0;
-    *out = h;
-    HIPCHK(h, hipSetDevice(s->device));
-    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->stream = nullptr;
     Dev& d = h->d;
     memset(&d, 0, sizeof d);
+    memset(&h->net, 0, sizeof h->net);
+    HIPCHK(h, hipSetDevice(s->device));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     d.G = s->games;
     d.T = s->mcts_threads;
     int C = s->node_capacity > 0 ? s->node_capacity : 16 * (s->mcts_simulations + 1);
     if (C < 64) C = 64;
-    if (C > 65534) C = 65534;
     d.C = C;
     d.H = next_pow2(2 * C);
     d.DMAX = std::min(C, 1024);
@@ -881,6 +919,7 @@ extern "C" int azr_engine_create(const azr_settings* s, azr_engine** out)
     HIPCHK(h, dmalloc(&d.counters, 1));
     HIPCHK(h, dmalloc(&d.active, 1));
     HIPCHK(h, dmalloc(&d.arena_taken, 1));
+    HIPCHK(h, dmalloc(&d.sp_started, 1));
     HIPCHK(h, dmalloc(&d.arena_res, 8));
     HIPCHK(h, dmalloc(&d.prev_start, G * GREC));
     HIPCHK(h, dmalloc(&d.script, G * 2 * 32));
@@ -909,9 +948,9 @@ extern "C" int azr_engine_destroy(azr_engine* h)
 {
     if (!h) return AZR_E_BAD_HANDLE;
     hipSetDevice(h->cfg.device);
-    hipStreamSynchronize(h->stream);
+    if (h->stream) hipStreamSynchronize(h->stream);
     Dev& d = h->d;
-    void* ptrs[] = {d.state, d.ctl, d.nodes, d.touch, d.nhash, d.table, d.freel, d.path, d.leaf_in, d.leaf_key,
+    void* ptrs[] = {d.sp_started, d.state, d.ctl, d.nodes, d.touch, d.nhash, d.table, d.freel, d.path, d.leaf_in, d.leaf_key,
                     d.leaf_valid, d.leaf_hash, d.net_pi, d.net_v, d.stage, d.ring, d.ring_count, d.counters, d.active,
                     d.arena_taken, d.arena_res, d.prev_start, d.script, d.alog_status, d.alog_rounds, d.alog_final};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -921,12 +960,16 @@ extern "C" int azr_engine_destroy(azr_engine* h)
     train_free(h);
     net_free(h);
     for (hipEvent_t e : h->ev) hipEventDestroy(e);
-    hipStreamDestroy(h->stream);
+    if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return AZR_OK;
 }
 
-extern "C" const char* azr_last_error(const azr_engine* h) { return h ? h->err.c_str() : "bad handle"; }
+extern "C" const char* azr_last_error(const azr_engine* h)
+{
+    if (h) return h->err.c_str();
+    return g_create_err.empty() ? "bad handle" : g_create_err.c_str();   // NULL: the calling thread's last failed create
+}
 extern "C" int azr_engine_games(const azr_engine* h) { return h ? h->d.G : 0; }
 
 // staging helpers: synchronous copies through temporary device buffers (boundary calls are not the hot path)
@@ -1188,16 +1231,31 @@ extern "C" int azr_mcts_pick(azr_engine* h, int sample, uint8_t* moves)
 }
 
 // ---- device-resident self-play ------------------------------------------------------------------------
-extern "C" int azr_selfplay_start(azr_engine* h, uint32_t base_seed)
+static int selfplay_start(azr_engine* h, uint32_t base_seed, unsigned long long quota)
 {
-    ENTER(h);
     h->d.base_seed = base_seed;
+    h->d.sp_quota = quota;
     h->mode = 2;
+    const unsigned long long started = quota ? std::min<unsigned long long>(quota, (unsigned long long)h->d.G) : 0ull;
+    HIPCHK(h, hipMemcpyAsync(h->d.sp_started, &started, sizeof started, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d.counters, 0, sizeof(Counters), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d.ring_count, 0, sizeof(unsigned long long), h->stream));
     LAUNCH(h, k_selfplay_start, h->d);
     SYNC(h);
     return AZR_OK;
+}
+
+extern "C" int azr_selfplay_start(azr_engine* h, uint32_t base_seed)
+{
+    ENTER(h);
+    return selfplay_start(h, base_seed, 0);
+}
+
+extern "C" int azr_selfplay_start_games(azr_engine* h, uint32_t base_seed, uint64_t games)
+{
+    ENTER(h);
+    if (games == 0) return AZR_E_INVALID_ARGUMENT;
+    return selfplay_start(h, base_seed, games);
 }
 
 extern "C" int azr_selfplay_run(azr_engine* h, int passes)
@@ -1263,6 +1321,7 @@ extern "C" int azr_selfplay_counters(azr_engine* h, azr_counters* out)
     out->simulations = c.simulations; out->evaluations = c.evaluations; out->levels = c.levels;
     out->decisions = c.decisions; out->games_finished = c.games_finished; out->samples = c.samples;
     out->nodes_dropped = c.nodes_dropped; out->errors = c.errors;
+    out->records_dropped = c.ring_dropped;
     return AZR_OK;
 }
 
@@ -1273,9 +1332,18 @@ extern "C" int azr_samples_drain(azr_engine* h, void* rec265, size_t cap, size_t
     D2H(h, &n, h->d.ring_count, 8);
     SYNC(h);
     if (n > h->d.ring_cap) n = h->d.ring_cap;
+    if (!rec265) cap = (size_t)n;   // no buffer: discard everything (reset of the ring)
     size_t take = std::min((size_t)n, cap);
     if (take && rec265) D2H(h, rec265, h->d.ring, take * AZR_RECORD_BYTES);
-    HIPCHK(h, hipMemsetAsync(h->d.ring_count, 0, 8, h->stream));
+    const unsigned long long left = n - take;
+    if (left) {  // partial drain: the records that did not fit move to the front of the ring and stay
+        DevBuf tmp;
+        HIPCHK(h, tmp.alloc((size_t)left * AZR_RECORD_BYTES));
+        HIPCHK(h, hipMemcpyAsync(tmp.p, h->d.ring + take * AZR_RECORD_BYTES, (size_t)left * AZR_RECORD_BYTES, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d.ring, tmp.p, (size_t)left * AZR_RECORD_BYTES, hipMemcpyDeviceToDevice, h->stream));
+        SYNC(h);
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d.ring_count, &left, 8, hipMemcpyHostToDevice, h->stream));
     SYNC(h);
     if (n_out) *n_out = take;
     return AZR_OK;
@@ -1290,6 +1358,21 @@ extern "C" int azr_samples_device_view(azr_engine* h, void** dev_ptr, size_t* n_
     if (n > h->d.ring_cap) n = h->d.ring_cap;
     if (dev_ptr) *dev_ptr = h->d.ring;
     if (n_out) *n_out = (size_t)n;
+    return AZR_OK;
+}
+
+extern "C" int azr_samples_copy_device(azr_engine* h, void* dst_device, size_t cap, size_t* n_out)
+{
+    ENTER(h);
+    unsigned long long n = 0;
+    D2H(h, &n, h->d.ring_count, 8);
+    SYNC(h);
+    if (n > h->d.ring_cap) n = h->d.ring_cap;
+    const size_t take = std::min((size_t)n, cap);
+    if (take && !dst_device) return AZR_E_INVALID_ARGUMENT;
+    if (take) HIPCHK(h, hipMemcpyAsync(dst_device, h->d.ring, take * AZR_RECORD_BYTES, hipMemcpyDeviceToDevice, h->stream));
+    SYNC(h);
+    if (n_out) *n_out = take;
     return AZR_OK;
 }
 

@@ -44,6 +44,8 @@ struct Dev {
     Counters* counters;
     uint32_t* active;      // number of games with a pending leaf after the last tree step
     uint32_t base_seed;
+    unsigned long long sp_quota;      // self-play quota mode: games to start in all (0 = unlimited)
+    unsigned long long* sp_started;   // ... and the ticket counter
     // arena (GameGroup::playGames, game/game.cpp:277-312)
     int kind0, kind1;          // AZR_PLAYER_* of player index 0 / 1
     int arena_total;           // Counter::count

@@ -22,6 +22,7 @@ using namespace azr;
     do {                                                                                        \
         hipError_t e__ = (call);                                                                \
         if (e__ != hipSuccess) {                                                                \
+            (void)hipGetLastError(); /* the runtime's last-error slot is sticky: clear it */        \
             (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
             return AZR_E_HIP;                                                                   \
         }                                                                                       \
@@ -445,12 +446,18 @@ extern "C" int azr_nn_load(azr_engine* h, const char* path)
     char magic[4];
     uint32_t ver = 0, blocks = 0;
     uint64_t count = 0;
+    // read into a temporary: a short or mismatching file must leave the handle's weights (host copy and device) untouched
+    std::vector<float> tmp;
     bool ok = fread(magic, 1, 4, f) == 4 && memcmp(magic, "AZRW", 4) == 0 && fread(&ver, 4, 1, f) == 1 &&
               fread(&blocks, 4, 1, f) == 1 && fread(&count, 8, 1, f) == 1 && ver == 1 &&
-              blocks == (uint32_t)h->net.blocks && count == h->flat.size() &&
-              fread(h->flat.data(), 4, count, f) == count;
+              blocks == (uint32_t)h->net.blocks && count == h->flat.size();
+    if (ok) {
+        tmp.resize(count);
+        ok = fread(tmp.data(), 4, count, f) == count && fgetc(f) == EOF;
+    }
     fclose(f);
-    if (!ok) { h->err = "bad or mismatching checkpoint"; return AZR_E_IO; }
+    if (!ok) { h->err = std::string("bad, truncated or mismatching checkpoint: ") + path; return AZR_E_IO; }
+    h->flat.swap(tmp);
     return net_upload(h);
 }
 

@@ -29,6 +29,7 @@ using namespace azr;
     do {                                                                                        \
         hipError_t e__ = (call);                                                                \
         if (e__ != hipSuccess) {                                                                \
+            (void)hipGetLastError(); /* the runtime's last-error slot is sticky: clear it */        \
             (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
             return AZR_E_HIP;                                                                   \
         }                                                                                       \

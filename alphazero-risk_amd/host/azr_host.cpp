@@ -476,17 +476,24 @@ SelfPlayReport AlphaZeroTrainer::generateTrainData(std::shared_ptr<AlphaZeroNNGr
         threads.emplace_back([&, i]() {  // one self-play thread per GPU (alphazero_trainer.cpp:48-57)
             Engine& e = *generate->getNN(i)->engine;
             const uint64_t share = target / P + ((uint64_t)i < target % P ? 1 : 0);
-            const uint32_t seed = SETTINGS.BASE_SEED + (uint32_t)i * (1u << 24) + (uint32_t)trainIteration * 65536u * (uint32_t)e.games;
-            e.check(azr_selfplay_start(e.h, seed), "selfplay_start");
+            if (share == 0) return;
+            // GPU i's seed stream: base + i * 2^24 + (games this GPU has started in earlier iterations) — no game of any
+            // (iteration, GPU) pair is ever replayed.  Exactly `share` games are started and every one is played to its
+            // end (Counter::hasNext over TRAIN_ITERATION_GAMES, alphazero_trainer.cpp:83).
+            if (selfPlayStarted.size() < (size_t)P) selfPlayStarted.resize(P, 0);
+            const uint32_t seed = SETTINGS.BASE_SEED + (uint32_t)i * (1u << 24) + (uint32_t)selfPlayStarted[i];
+            selfPlayStarted[i] += share;
+            e.check(azr_selfplay_start_games(e.h, seed, share), "selfplay_start_games");
             azr_counters c{};
-            std::vector<uint8_t> buf;
-            while (c.games_finished < share) {
+            std::vector<uint8_t> buf((size_t)e.games * 512 * AZR_RECORD_BYTES);
+            while (c.games_finished + c.errors < share) {
                 e.check(azr_selfplay_run(e.h, 4 * (SETTINGS.MCTS_SIMULATIONS + 2)), "selfplay_run");
                 e.check(azr_selfplay_counters(e.h, &c), "counters");
-                size_t n = 0;
-                buf.resize((size_t)e.games * 4096 * AZR_RECORD_BYTES / 8);
-                e.check(azr_samples_drain(e.h, buf.data(), buf.size() / AZR_RECORD_BYTES, &n), "drain");
-                storageGroup[i].appendPacked(buf.data(), n);
+                if (c.records_dropped) throw std::runtime_error("self-play records were dropped (sample_capacity too small)");
+                for (size_t n = buf.size() / AZR_RECORD_BYTES; n == buf.size() / AZR_RECORD_BYTES;) {  // a partial drain keeps the rest
+                    e.check(azr_samples_drain(e.h, buf.data(), buf.size() / AZR_RECORD_BYTES, &n), "drain");
+                    storageGroup[i].appendPacked(buf.data(), n);
+                }
                 printf("\r[gpu %d] games %llu/%llu  decisions %llu  simulations %llu", i, (unsigned long long)c.games_finished,
                        (unsigned long long)share, (unsigned long long)c.decisions, (unsigned long long)c.simulations);
                 fflush(stdout);
@@ -572,10 +579,11 @@ GameResults GameGroup::playGames(AlphaZeroPlayerGroup& pg1, AlphaZeroPlayerGroup
                 e.check(azr_arena_run(e.h, 4 * (SETTINGS.MCTS_SIMULATIONS + 2), &fin), "arena_run");
                 e.check(azr_arena_results(e.h, &res[i]), "arena_results");
                 if (tds) {
-                    size_t n = 0;
-                    buf.resize((size_t)e.games * 4096 * AZR_RECORD_BYTES / 8);
-                    e.check(azr_samples_drain(e.h, buf.data(), buf.size() / AZR_RECORD_BYTES, &n), "drain");
-                    st[i].appendPacked(buf.data(), n);
+                    buf.resize((size_t)e.games * 512 * AZR_RECORD_BYTES);
+                    for (size_t n = buf.size() / AZR_RECORD_BYTES; n == buf.size() / AZR_RECORD_BYTES;) {
+                        e.check(azr_samples_drain(e.h, buf.data(), buf.size() / AZR_RECORD_BYTES, &n), "drain");
+                        st[i].appendPacked(buf.data(), n);
+                    }
                 }
                 if (i == 0) {
                     printf("\r%d/%d [Draw/P1,P2]: %d, %d/%d, %d/%d", res[i].count, share, res[i].draw, res[i].win[0], res[i].win_and_started[0],

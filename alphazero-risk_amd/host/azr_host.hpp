@@ -243,6 +243,7 @@ class AlphaZeroTrainer {  // alphazero_trainer.h
 public:
     NNTrainDataStorage trainStorage;
     long trainIteration = 0;
+    std::vector<uint64_t> selfPlayStarted;   // per GPU: self-play games started so far (seed stream position)
     // generateTrainData (alphazero_trainer.cpp:36-78): one host thread per GPU, TRAIN_ITERATION_GAMES games in total,
     // device-resident self-play; the per-GPU storages are concatenated in GPU order
     SelfPlayReport generateTrainData(std::shared_ptr<AlphaZeroNNGroup> generate);

@@ -2,9 +2,8 @@
 over the MI355X engine:
 
     self-play (device-resident, azr_selfplay_*)  ->  replay buffer (trimOldExamples, alphazero_nn_data.cpp:67-84)
-    ->  train step (azr_nn_train: the HIP optimiser step of csrc/azr_train.hip; `--trainer torch` selects the PyTorch
-        cross-check implementation in train.py)  ->  arena new-vs-old through the batched Player seam
-    (two engines = two nets, one tree per player as in the reference)  ->  accept (>= COMPARE_TRESHOLD of decided games)
+    ->  train step (azr_nn_train: the HIP optimiser step of csrc/azr_train.hip)  ->  arena new-vs-old resident on the
+    device (two engines = two nets, one tree per player as in the reference)  ->  accept (>= COMPARE_TRESHOLD of decided games)
     / revert  ->  benchmark vs RandomPlayer(10) and ScriptPlayer(100) on the device arena
 with the reference's log files (log/azr-improvement-log.txt, azr-benchmark-log.txt, azr-nn-training-log.txt) and
 checkpoint names (checkpoints/{latest,best}-checkpoint.bin, checkpoint-iter-N.bin; AZRW container).
@@ -29,77 +28,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 P = importlib.import_module("alphazero-risk_amd")
-train_mod = importlib.import_module("alphazero-risk_amd.train")
 shard_mod = importlib.import_module("alphazero-risk_amd.shard")
-
-
-# ---- host-side pieces of Game (game/game.cpp) for the two-net arena ---------------------------------------------------
-def invert_players(img):
-    """State::invertPlayers (state.cpp:493-516) on [G,160] Data images"""
-    out = img.copy()
-    la = out[:, :42]
-    owner = la >> 6
-    out[:, :42] = np.where(owner < 2, (la & 63) | ((owner ^ 1) << 6), la)
-    out[:, 48:96], out[:, 96:144] = img[:, 96:144], img[:, 48:96]
-    return out
-
-
-def take_turns(eng, states, me):
-    """AlphaZeroPlayerGroup::takeTurns = batched AlphaZeroPlayer::takeTurn (alphazero_player.cpp:3-21)"""
-    eng.mcts_trim()
-    while True:
-        eng.set_states(states)
-        status = eng.status()
-        mine = (status == -1) & (states[:, 146] == me)
-        if not mine.any():
-            return states
-        eng.simulate()
-        mv = eng.pick(sample=False)
-        mv[~mine] = 255
-        eng.make_moves(mv)
-        states = eng.get_states()
-
-
-def arena_two_nets(eng_new, eng_old, games, mirror=True, base_seed=1):
-    """GameGroup::playGames(trainAZPG, generateAZPG, games) (game.cpp:277-312): player 0 = new net, player 1 = old net.
-    The G slots play mirrored pairs in lock-step.  Returns a GameResults-like dict."""
-    G = eng_new.G
-    res = dict(count=0, draw=0, win=[0, 0], win_and_started=[0, 0])
-    seed = base_seed
-    while True:
-        take = min(G, (games - res["count"]) // 2)   # Counter::hasNext(2): whole pairs only; slot k plays pair k
-        if take == 0:
-            return res
-        eng_new.new_games(np.arange(seed, seed + G, dtype=np.uint32))
-        seed += G
-        start = eng_new.get_states()
-        for player_start in (0, 1):   # Game::newGame (game.cpp:170-191) + incPlayerStart
-            if player_start == 0:
-                states = start.copy()
-            elif mirror:
-                states = invert_players(start)
-            else:
-                eng_new.new_games(np.arange(seed, seed + G, dtype=np.uint32))
-                seed += G
-                states = eng_new.get_states()
-            states[:, 146] = player_start          # State::setCurrentPlayerTurn
-            eng_new.mcts_clear()                   # AlphaZeroPlayer::newGame
-            eng_old.mcts_clear()
-            while True:                            # Game::gameLoop
-                states = take_turns(eng_new, states, 0)
-                states = take_turns(eng_old, states, 1)
-                eng_new.set_states(states)
-                status = eng_new.status()
-                if (status != -1).all():
-                    break
-            for g in range(take):                  # GameResults::addGame (game.cpp:193-213)
-                res["count"] += 1
-                if status[g] == -2:
-                    res["draw"] += 1
-                else:
-                    res["win"][status[g]] += 1
-                    if status[g] == player_start:
-                        res["win_and_started"][status[g]] += 1
 
 
 def arena_device(eng_new, eng_old, games, mirror=True, base_seed=1, collect=False):
@@ -158,9 +87,6 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
     os.makedirs("checkpoints", exist_ok=True)
     dtype = P.NET_BF16 if a.dtype == "bf16" else P.NET_F32
     t = getattr(a, "t", 2)
-    if getattr(a, "trainer", "native") == "torch":
-        import torch   # torch bundles its own HIP runtime: it has to initialise the device before the C-ABI library does
-        torch.cuda.init()
     if rank != 0:
         log = lambda *_: None   # noqa: E731  (rank 0 reports)
     gen = P.Engine(a.gpu_games, blocks=a.blocks, sims=a.mcts, dtype=dtype, device=a.device, threads=t)
@@ -174,12 +100,10 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
         dist.barrier()
     for e in (new, gen):
         e.load(latest)
-    trainer = None
-    if getattr(a, "trainer", "native") == "torch":
-        trainer = train_mod.Trainer(a.blocks, new.get_weights(), device=f"cuda:{a.device}", batch_size=a.bs, seed=a.seed)
     shuffle_state = a.seed % 2147483646 + 1   # raw minstd_rand0 state standing in for the reference's global RNG
     records = np.zeros((0, 265), np.uint8)
     old_game_index = 0
+    games_started = 0   # self-play games this rank has started in earlier iterations (its position in its seed stream)
     sink = "/dev/null" if rank else None
     imp_log = open(sink or "log/azr-improvement-log.txt", "a")
     bench_log = open(sink or "log/azr-benchmark-log.txt", "a")
@@ -190,15 +114,19 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
         # ---- generateTrainData (alphazero_trainer.cpp:36-78)
         t0 = time.time()
         share = shard_mod.split_count(a.tg, world, rank)   # one self-play shard per GPU (alphazero_trainer.cpp:41-57)
-        gen.selfplay_start(shard_mod.rank_base_seed((a.seed + it * 65536 * a.gpu_games) & 0xFFFFFFFF, rank))
         new_recs = [np.zeros((0, 265), np.uint8)]
-        c = gen.counters()
-        while share > 0:
-            gen.selfplay_run(4 * (a.mcts + 2))
-            c = gen.counters()
-            new_recs.append(gen.drain())
-            if c["games_finished"] >= share:
-                break
+        c = dict(games_finished=0, simulations=0, errors=0)
+        if share > 0:
+            # exactly `share` games, each played to its end (Counter::hasNext, alphazero_trainer.cpp:83); this rank's seed
+            # stream continues where its previous iteration stopped, so no (iteration, rank) pair ever replays a game
+            gen.selfplay_start_games(shard_mod.selfplay_seed(a.seed, rank, games_started), share)
+            games_started += share
+            while c["games_finished"] + c["errors"] < share:
+                gen.selfplay_run(4 * (a.mcts + 2))
+                c = gen.counters()
+                new_recs.append(gen.drain())
+            if c["records_dropped"]:
+                raise RuntimeError(f"{c['records_dropped']} self-play records were dropped: raise sample_capacity")
         new_recs = np.concatenate(new_recs)
         if dist is not None:   # the one exchange step of data generation: records of all shards, in rank order
             import torch
@@ -213,13 +141,9 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
         t0 = time.time()
         hist = []
         if rank == 0:   # AlphaZeroNNGroup::train: the first GPU trains (alphazero_gpu_cluster.cpp:221-231)
-            if trainer is not None:
-                hist = trainer.train(records, a.e, nn_log)
-                new.set_weights(trainer.flat())
-            else:
-                hist, shuffle_state = new.train(records, a.e, batch_size=a.bs, rng_state=shuffle_state)
-                hist = [h for h in hist if not np.isnan(h[0])]
-                nn_log.write("".join(f"{lp}, {lv}, " for lp, lv in hist) + "\n"); nn_log.flush()
+            hist, shuffle_state = new.train(records, a.e, batch_size=a.bs, rng_state=shuffle_state)
+            hist = [h for h in hist if not np.isnan(h[0])]
+            nn_log.write("".join(f"{lp}, {lv}, " for lp, lv in hist) + "\n"); nn_log.flush()
         if dist is not None:   # ... and the others receive its weights
             w = shard_mod.broadcast_flat(new.get_weights(), dist, src=0, device=cdev)
             if rank != 0:
@@ -234,10 +158,7 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
         if a.cg > 0:
             share = 2 * shard_mod.split_count(a.cg // 2, world, rank)
             aseed = shard_mod.rank_base_seed(a.seed + 7919 * (it + 1), rank)
-            if getattr(a, "arena", "device") == "host":
-                gr, arecs = arena_two_nets(new, gen, share, True, aseed), np.zeros((0, 265), np.uint8)
-            else:
-                gr, arecs = arena_device(new, gen, share, True, aseed, collect=bool(getattr(a, "include_compare_samples", 1)))
+            gr, arecs = arena_device(new, gen, share, True, aseed, collect=bool(getattr(a, "include_compare_samples", 1)))
             if dist is not None:
                 gr = reduce_results(gr, dist, cdev)
                 import torch
@@ -266,8 +187,6 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
         else:
             log("Model did not improve\nModel reverted back old")
             new.load(latest)
-            if trainer is not None:
-                trainer.load_flat(new.get_weights())
         summary.append(dict(iteration=it, samples=len(records), losses=hist, arena=gr, improved=improved))
     # saveTrainingSamples (reference writer layout: 8-byte count + 265-byte records)
     if rank == 0:
@@ -295,9 +214,6 @@ def main():
     ap.add_argument("--seed", type=int, default=20260001)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("--trainer", default="native", choices=["native", "torch"])
-    ap.add_argument("--arena", default="device", choices=["device", "host"],
-                    help="new-vs-old compare games resident on the device (default) or stepped from the host through the Player seam")
     ap.add_argument("--include-compare-samples", type=int, default=1)   # INCLUDE_COMPARE_GAMES_TRAIN_SAMPLES
     a = ap.parse_args()
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))

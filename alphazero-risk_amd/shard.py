@@ -17,6 +17,15 @@ def rank_base_seed(base_seed, rank):
     return (int(base_seed) + int(rank) * SEED_STRIDE) & 0xFFFFFFFF
 
 
+def selfplay_seed(base_seed, rank, games_started):
+    """first seed of a rank's next batch of self-play games: base + rank * 2^24 + (games this rank has started so far).
+    With azr_selfplay_start_games (game i of the batch plays seed + i) every game of every (iteration, rank) pair has
+    its own seed as long as a rank starts fewer than 2^24 games in all."""
+    if games_started >= SEED_STRIDE:
+        raise ValueError("a rank's seed range (2^24 games) is exhausted")
+    return (int(base_seed) + int(rank) * SEED_STRIDE + int(games_started)) & 0xFFFFFFFF
+
+
 def gather_records(records, dist=None, device=None):
     """all ranks contribute a uint8 tensor [n_r, 265]; every rank gets the concatenation in rank order.
     Padded all_gather: counts first, then buffers padded to the maximum count."""
@@ -67,17 +76,33 @@ def broadcast_flat(flat, dist=None, src=0, device="cpu"):
     return t.cpu().numpy()
 
 
-def device_records_to_torch(ptr, n, device):
-    """copy n packed records from the engine's device ring (raw pointer) into a torch uint8 tensor on `device`"""
-    import ctypes as C
-
+def device_records_to_torch(eng, device):
+    """the engine's finished records as a torch uint8 tensor [n, 265] on `device` (the GPU the engine runs on): one
+    device-to-device copy on the engine's own stream (azr_samples_copy_device) — the send buffer of the record gather.
+    The records stay buffered in the engine."""
     import torch
 
+    _one_hip_runtime()
+    n = eng.samples_device_view()[1]
     out = torch.empty((n, RECORD_BYTES), dtype=torch.uint8, device=device)
     if n:
-        hip = C.CDLL("libamdhip64.so")
-        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        rc = hip.hipMemcpy(C.c_void_p(out.data_ptr()), C.c_void_p(ptr), n * RECORD_BYTES, 3)  # hipMemcpyDeviceToDevice
-        if rc:
-            raise RuntimeError(f"hipMemcpy failed: {rc}")
+        got = eng.samples_copy_device(out.data_ptr(), n)
+        if got != n:
+            raise RuntimeError(f"azr_samples_copy_device copied {got} of {n} records")
     return out
+
+
+def _one_hip_runtime():
+    """torch ships its own libamdhip64 (same soname as /opt/rocm's).  Imported FIRST, the C-ABI library binds to it too
+    and both sides share one runtime; loaded the other way round the process holds two runtimes and a pointer of one
+    means nothing to the other.  Refuse that state instead of copying through it."""
+    libs = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    libs.add(line.split()[-1])
+    except OSError:
+        return
+    if len(libs) > 1:
+        raise RuntimeError("two HIP runtimes are mapped (%s): import torch BEFORE creating the first Engine" % ", ".join(sorted(libs)))

@@ -1,21 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — MCTS simulations/s of device-resident AlphaZero-Risk self-play on MI355X.
 
-Workload (BASELINE.json configs[1]): 256 concurrent self-play games per GPU, 100 MCTS simulations per move,
-random-init 20-block / 256-filter net, bf16 MFMA contractions with fp32 accumulation.  One "step" = one pass of
-the hot path over the batch of games: a tree step (expand + backup of the previous leaves, PUCT descent to the
-next leaves — and, when a search completes, the move, the record and possibly a game restart — for all G games)
-followed by one batched net evaluation of the G leaves.  Everything is resident in HBM; nothing crosses PCIe in
-the timed region except the final counters.  Multi-GPU: one process per GPU, games sharded, no data-path
-collective; one RCCL all_gather of the finished (s, pi, z) records closes the timed region (weak scaling).
+Headline workload = the point BASELINE.json's north_star quotes the metric on: 512 concurrent self-play games per
+GPU, 100 MCTS simulations per move, THREADS_PER_MCTS 2 (the reference's default, src/settings.h:44), random-init
+20-block / 256-filter net, bf16 MFMA contractions with fp32 accumulation.  At N = 1 the other two single-GPU
+configurations of BASELINE.json (configs[1] 256 x 100 and configs[2] 2048 x 400) run in the same invocation and are
+reported under "extra_configs", each with its own roofline.
 
-    python bench.py [--gpus N --steps K --warmup W] [--games 256 --sims 100 --blocks 20 --dtype bf16]
+One "step" = one MOVE's worth of the hot path for every game of the batch: S/T + 1 passes, a pass being one tree step
+(expand + backup of the previous leaves, PUCT descents to the next leaves — and, when a search completes, the move,
+the (s, pi) record and possibly a game restart — for all G games) followed by one batched net evaluation of the
+G x T leaf slots.  --steps K times exactly K x (S/T + 1) passes.  Everything is resident in HBM; nothing crosses PCIe
+in the timed region except the final counters.
+
+Multi-GPU (weak scaling): one process per GPU, games sharded with disjoint seed streams, NO data-path collective.
+`python bench.py --gpus N` starts the N ranks itself (before anything touches torch or HIP); under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one of them.  The path's one exchange — the
+all_gather of finished (s, pi, z) records, alphazero_trainer.cpp:59-62 — is measured on real records after an untimed
+tail that plays games to their end, and reported under "exchange" (records, bytes, gather_ms).
+
+    python bench.py [--gpus N --steps K --warmup W] [--games 512 --sims 100 --threads 2 --blocks 20 --dtype bf16]
 """
 import argparse
 import ctypes as C
-import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +36,8 @@ sys.path.insert(0, ROOT)
 FLOP_PER_SIM = {20: 2 * 797_976_348, 5: 2 * 200_288_028}  # valid (un-padded) taps only
 PEAK_BF16 = 2.5e15   # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32 = 157.3e12  # fp32 vector/matrix
+EXTRA_CONFIGS = [(256, 100, 2), (2048, 400, 2)]   # BASELINE.json configs[1], configs[2] (games, sims/move, THREADS_PER_MCTS)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by tools/pmc_summary.py from rocprofv3 --pmc runs
 
 
 def flop_per_sim(blocks):
@@ -32,6 +45,21 @@ def flop_per_sim(blocks):
         return FLOP_PER_SIM[blocks]
     mac = 304 * 13 * 256 + blocks * 2 * 304 * 256 * 256 + 46_876
     return 2 * mac
+
+
+def config_key(games, sims, threads, blocks, dtype):
+    return f"g{games}_s{sims}_t{threads}_b{blocks}_{dtype}"
+
+
+def measured_traffic(games, sims, threads, blocks, dtype):
+    """HBM-side bytes per launch of the dominant kernel for exactly this configuration, from the committed rocprofv3 PMC
+    summary (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md) — None when no profile of this
+    configuration has been taken."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            return json.load(f).get(config_key(games, sims, threads, blocks, dtype), {}).get("bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(blocks, sims, mcts_threads, seconds_budget=25.0):
@@ -63,28 +91,207 @@ def cpu_baseline(blocks, sims, mcts_threads, seconds_budget=25.0):
                       f"{blocks}-block fp32 CPU net, {sec.value:.1f} s"}
 
 
+def spawn_ranks(a, argv):
+    """`python bench.py --gpus N` outside a launcher: this parent has not imported torch nor touched HIP; it starts one
+    fresh child per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relays rank 0's JSON line and fails if any rank
+    fails.  (Never an exec from a process that has initialised the GPU.)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit(f"bench.py: rank exit codes {rcs}")
+    line = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
+    if not line or json.loads(line[-1]).get("n_gpus") != a.gpus:
+        raise SystemExit("bench.py: rank 0 did not report n_gpus == --gpus")
+
+
+def run_config(ctx, games, sims, threads, steps, warmup, tail):
+    """K steps of one configuration on this rank's GPU; returns the per-rank measurements (reduced by the caller)"""
+    a, pkg, shard, torch, dist = ctx["a"], ctx["pkg"], ctx["shard"], ctx["torch"], ctx["dist"]
+    rank, world, local, dev, cdev = ctx["rank"], ctx["world"], ctx["local"], ctx["dev"], ctx["cdev"]
+    passes_per_step = sims // threads + 1   # setRootState's root expansion + (S - S % T) / T lock-stepped rounds
+    eng = pkg.Engine(games, blocks=a.blocks, sims=sims, dtype=pkg.NET_BF16 if a.dtype == "bf16" else pkg.NET_F32,
+                     device=local, threads=threads)
+    eng.init_random(20260002)
+    eng.selfplay_start(shard.rank_base_seed(20260001, rank))
+
+    def barrier():
+        torch.cuda.synchronize()
+        eng.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t_start = time.perf_counter()
+    eng.selfplay_run(warmup * passes_per_step)
+    c0 = eng.counters()
+    barrier()
+    t0 = time.perf_counter()
+    # EXACTLY K steps = K x passes_per_step passes, issued in up to 10 slices so that a median rate can be reported next
+    # to the mean (SURVEY 8d); a slice boundary is one counter read-back (a stream sync of a few microseconds)
+    chunk_rates, profs, done, prev_sims, prev_t = [], [], 0, c0["simulations"], t0
+    for i in range(10):
+        n = (steps * (i + 1)) // 10 - done
+        if n <= 0:
+            continue
+        eng.selfplay_run(n * passes_per_step)
+        done += n
+        now, cs = time.perf_counter(), eng.counters()["simulations"]
+        chunk_rates.append((cs - prev_sims) / max(now - prev_t, 1e-9))
+        profs.append(eng.profile_last_run())
+        prev_sims, prev_t = cs, now
+    barrier()
+    dt = time.perf_counter() - t0
+    c1 = eng.counters()
+    # HIP-event timings of the kernels (on the engine's stream), launch-weighted over the slices of the timed region
+    nl = max(1, sum(p_["launches"] for p_ in profs))
+    prof = {"net_ms": sum(p_["net_ms"] * p_["launches"] for p_ in profs) / nl,
+            "tree_ms": sum(p_["tree_ms"] * p_["launches"] for p_ in profs) / nl, "launches": sum(p_["launches"] for p_ in profs)}
+    delta = {k: c1[k] - c0[k] for k in c1}
+    keys = ["simulations", "evaluations", "levels", "decisions", "games_finished", "samples", "errors", "nodes_dropped",
+            "records_dropped"]
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    tot = torch.tensor([delta[k] for k in keys], dtype=torch.int64, device=cdev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    tot = dict(zip(keys, (int(x) for x in tot.tolist())))
+
+    # untimed tail: play on until a quarter of this rank's games have finished (bounded), which gives whole self-play
+    # games/s and REAL finished records for the path's one exchange step; then time that exchange on its own
+    games_rate, exchange = None, None
+    if tail:
+        t_tail = time.perf_counter()
+        while time.perf_counter() - t_tail < a.tail_seconds:
+            eng.selfplay_run(40 * passes_per_step)
+            if eng.counters()["games_finished"] >= max(1, games // 4):
+                break
+        ct = eng.counters()
+        el = time.perf_counter() - t_start
+        fin = torch.tensor([ct["games_finished"], ct["samples"], ct["simulations"]], dtype=torch.float64, device=cdev)
+        elt = torch.tensor([el], dtype=torch.float64, device=cdev)
+        if world > 1:
+            dist.all_reduce(fin, op=dist.ReduceOp.SUM)
+            dist.all_reduce(elt, op=dist.ReduceOp.MAX)
+        gf, smp, sm = fin.tolist()
+        el = float(elt.item())
+        if gf > 0:
+            games_rate = {"games_per_s": gf / el, "games": int(gf), "decisions_per_finished_game": smp / gf,
+                          "window_s": el, "simulations_per_s_over_window": sm / el}
+        # the exchange: every rank's finished records, device-to-device into the send buffer, padded all_gather (RCCL over
+        # xGMI at N > 1; at N = 1 the same code path without the collective)
+        barrier()
+        tg = time.perf_counter()
+        recs = shard.device_records_to_torch(eng, dev)
+        allrecs = shard.gather_records(recs if cdev == dev else recs.to(cdev), dist if world > 1 else None)
+        barrier()
+        gms = 1e3 * (time.perf_counter() - tg)
+        gt = torch.tensor([gms], dtype=torch.float64, device=cdev)
+        if world > 1:
+            dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+        exchange = {"records_gathered": int(allrecs.shape[0]), "bytes": int(allrecs.shape[0]) * 265,
+                    "records_this_rank": int(recs.shape[0]), "gather_ms": float(gt.item()),
+                    "self_play_window_s": el, "fraction_of_window": float(gt.item()) * 1e-3 / el,
+                    "collective": "all_gather (counts) + padded all_gather (records), backend %s" % ctx["backend"]
+                                  if world > 1 else "none at N = 1 (device copy of the record ring only)"}
+        assert ct["records_dropped"] == 0, "records were dropped: raise sample_capacity"
+    eng.close()
+
+    fps = flop_per_sim(a.blocks)
+    net_s = prof["net_ms"] * 1e-3
+    npass = steps * passes_per_step
+    # algorithmic work of one launch = the leaves that were actually waiting for the net (idle slots are not counted)
+    leaves_per_launch = tot["evaluations"] / max(1, npass * world)
+    achieved = leaves_per_launch * fps / net_s if net_s > 0 else 0.0
+    peak = PEAK_BF16 if a.dtype == "bf16" else PEAK_F32
+    sims_total, levels = tot["simulations"], tot["levels"]
+    out = {
+        "value": sims_total / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+        "passes_per_step": passes_per_step, "timed_region_s": dt,
+        "config": {"workload": f"{games} concurrent self-play games/GPU x {sims} MCTS sims/move, THREADS_PER_MCTS {threads}, "
+                               f"{a.blocks}-block 256-filter random-init net, {a.dtype}",
+                   "games_per_gpu": games, "sims_per_move": sims, "mcts_threads": threads, "blocks": a.blocks,
+                   "step": f"one move for every game = {passes_per_step} passes (tree step + net forward of {games * threads} leaf slots)",
+                   "parallelism": f"games sharded x{world}, no data-path collective; 1 all_gather of finished records per iteration"},
+        "simulations_per_s_p50_rank0": sorted(chunk_rates)[len(chunk_rates) // 2] if chunk_rates else None,
+        "self_play_games_per_s": games_rate["games_per_s"] if games_rate else None,
+        "self_play_games_window": games_rate, "decisions_per_s": tot["decisions"] / dt,
+        "net_evals_per_s": tot["evaluations"] / dt, "mean_depth": levels / max(1, sims_total),
+        "games_finished_in_timed_region": tot["games_finished"], "errors": tot["errors"],
+        "nodes_dropped": tot["nodes_dropped"], "records_dropped": tot["records_dropped"],
+        "roofline": {"bound": "mfma", "kernel": "k_tower_bf16 (one whole net forward of the G x T leaf slots: stem + 2B conv layers + both heads, one launch)"
+                     if a.dtype == "bf16" else "fp32 conv chain", "achieved": achieved / 1e12,
+                     "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "flop_per_launch": leaves_per_launch * fps, "leaves_per_launch": leaves_per_launch,
+                     "leaf_slots_per_launch": games * threads, "avg_launch_ms": prof["net_ms"],
+                     "tree_step_avg_ms": prof["tree_ms"], "timed_launches": prof["launches"],
+                     # HBM-side bytes per launch from the committed rocprofv3 PMC summary of THIS configuration (null if none)
+                     "traffic": measured_traffic(games, sims, threads, a.blocks, a.dtype)},
+    }
+    if exchange:
+        out["exchange"] = exchange
+        out["records_gathered"] = exchange["records_gathered"]
+    # the HBM-side part of a simulation (SURVEY 8d): node reads / backup writes per tree level, leaf record, prior and
+    # node write per evaluation, state + control block per game and pass.  One wavefront walks one game's tree, so
+    # this kernel is bound by dependent-access latency, not by bandwidth: the fraction below says how far from it.
+    lv, ev = levels / max(1, world), tot["evaluations"] / max(1, world)
+    tree_bytes = lv * (640 + 64 + 12 + 4) + ev * (96 + 64 + 16 + 176 + 4 + 640 + 8) + npass * games * (64 + 128) * 2
+    tree_s = prof["tree_ms"] * 1e-3 * npass
+    out["tree_step"] = {"bound": "hbm", "kernel": "k_tree_step (select / expand / backup / decision for every game, one wavefront each)",
+                        "achieved": tree_bytes / tree_s / 1e9 if tree_s > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
+                        "frac": tree_bytes / tree_s / 8e12 if tree_s > 0 else 0.0,
+                        "bytes_per_simulation": tree_bytes / max(1.0, sims_total / max(1, world)), "avg_launch_ms": prof["tree_ms"],
+                        "share_of_step": prof["tree_ms"] * npass / (1e3 * dt) if dt > 0 else None,
+                        "note": "latency-bound pointer chasing (mean depth %.2f)" % (levels / max(1, sims_total))}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3000)
-    ap.add_argument("--warmup", type=int, default=300)
-    ap.add_argument("--games", type=int, default=256, help="concurrent games per GPU")
+    ap.add_argument("--steps", type=int, default=20, help="timed steps; a step = one move for every game = sims/threads + 1 passes")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--games", type=int, default=512, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=100)
     ap.add_argument("--threads", type=int, default=2,
                     help="THREADS_PER_MCTS (-t): search threads per game; 2 is the reference's default (src/settings.h:44)")
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip BASELINE configs[1] / configs[2] (N = 1 runs them by default)")
     ap.add_argument("--no-full-games", action="store_true",
-                    help="skip the untimed tail that plays on until G games have finished (self-play games/s)")
+                    help="skip the untimed tail (whole self-play games/s, and the record exchange on real records)")
+    ap.add_argument("--tail-seconds", type=float, default=75.0)
     a = ap.parse_args()
+    if a.gpus < 1 or a.steps < 1 or a.warmup < 0:
+        raise SystemExit("bench.py: --gpus >= 1, --steps >= 1, --warmup >= 0")
 
-    import torch
-    import torch.distributed as dist
-
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        return spawn_ranks(a, sys.argv[1:])          # before torch / HIP are touched
+    world = int(env_world or "1")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus}, or plain python bench.py --gpus {a.gpus})")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import importlib
+
+    import torch                      # first: the C-ABI library then binds to the same HIP runtime (shard._one_hip_runtime)
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path is the only path (no CPU fallback)")
     # backend "nccl" IS RCCL on ROCm.  AZR_BENCH_BACKEND=gloo is a rehearsal switch for boxes with fewer GPUs than
@@ -103,127 +310,34 @@ def main():
             dist.init_process_group(backend)
 
     pkg = importlib.import_module("alphazero-risk_amd")
-    from importlib import import_module
-    shard = import_module("alphazero-risk_amd.shard")
-    eng = pkg.Engine(a.games, blocks=a.blocks, sims=a.sims, dtype=pkg.NET_BF16 if a.dtype == "bf16" else pkg.NET_F32,
-                     device=local, threads=a.threads)
-    eng.init_random(20260002)
-    eng.selfplay_start(shard.rank_base_seed(20260001, rank))
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    t_start = time.perf_counter()
-    eng.selfplay_run(a.warmup)
-    eng.drain(1)  # reset the record ring
-    c0 = eng.counters()
-    barrier()
-    t0 = time.perf_counter()
-    # EXACTLY K passes, issued in 10 slices so that a median rate can be reported next to the mean; a slice
-    # boundary is one counter read-back (a stream sync of a few microseconds)
-    chunk_rates, profs, done, prev_sims, prev_t = [], [], 0, c0["simulations"], t0
-    for i in range(10):
-        n = (a.steps * (i + 1)) // 10 - done
-        if n <= 0:
-            continue
-        eng.selfplay_run(n)
-        done += n
-        now, cs = time.perf_counter(), eng.counters()["simulations"]
-        chunk_rates.append((cs - prev_sims) / max(now - prev_t, 1e-9))
-        profs.append(eng.profile_last_run())
-        prev_sims, prev_t = cs, now
-    ptr, nrec = eng.samples_device_view()
-    recs = shard.device_records_to_torch(ptr, nrec, dev)
-    allrecs = shard.gather_records(recs.to(cdev), dist if world > 1 else None)   # the path's one exchange step
-    barrier()
-    dt = time.perf_counter() - t0
-    c1 = eng.counters()
-    # HIP-event timings of the kernels (on the engine's stream), launch-weighted over the slices of the timed region
-    nl = max(1, sum(p_["launches"] for p_ in profs))
-    prof = {"net_ms": sum(p_["net_ms"] * p_["launches"] for p_ in profs) / nl,
-            "tree_ms": sum(p_["tree_ms"] * p_["launches"] for p_ in profs) / nl, "launches": sum(p_["launches"] for p_ in profs)}
-
-    delta = {k: c1[k] - c0[k] for k in c1}
-    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-    tot = torch.tensor([delta["simulations"], delta["evaluations"], delta["levels"], delta["decisions"],
-                        delta["games_finished"], delta["samples"], delta["errors"], delta["nodes_dropped"]],
-                       dtype=torch.int64, device=cdev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    dt = float(tmax.item())
-    sims, evals, levels, decisions, games, samples, errors, dropped = [int(x) for x in tot.tolist()]
-
-    # untimed tail (N = 1 only): keep playing until G games have finished to measure whole self-play games/s
-    games_rate = None
-    if world == 1 and not a.no_full_games:
-        t_tail = time.perf_counter()
-        while time.perf_counter() - t_tail < 120.0:
-            eng.selfplay_run(2000)
-            eng.drain(1)
-            ct = eng.counters()
-            if ct["games_finished"] >= a.games:
-                break
-        ct = eng.counters()
-        el = time.perf_counter() - t_start
-        if ct["games_finished"] > 0:
-            games_rate = {"games_per_s": ct["games_finished"] / el, "games": ct["games_finished"],
-                          "decisions_per_finished_game": ct["samples"] / ct["games_finished"],
-                          "window_s": el, "simulations_per_s_over_window": ct["simulations"] / el}
-
+    shard = importlib.import_module("alphazero-risk_amd.shard")
+    ctx = dict(a=a, pkg=pkg, shard=shard, torch=torch, dist=dist, rank=rank, world=world, local=local, dev=dev, cdev=cdev,
+               backend=backend)
+    head = run_config(ctx, a.games, a.sims, a.threads, a.steps, a.warmup, tail=not a.no_full_games)
+    extras = []
+    if world == 1 and not a.no_extra:
+        for g, s, t in EXTRA_CONFIGS:
+            if (g, s, t) == (a.games, a.sims, a.threads):
+                continue
+            # the same number of net launches as the headline region, at least 2 steps
+            k = max(2, (a.steps * (a.sims // a.threads + 1)) // (s // t + 1))
+            w = max(1, (a.warmup * (a.sims // a.threads + 1)) // (s // t + 1))
+            e = run_config(ctx, g, s, t, k, w, tail=False)
+            e["metric"], e["unit"] = "MCTS simulations/s", "simulations/s"
+            extras.append(e)
     if rank == 0:
-        fps = flop_per_sim(a.blocks)
-        net_s = prof["net_ms"] * 1e-3
-        # algorithmic work of one launch = the leaves that were actually waiting for the net (idle slots are not counted)
-        leaves_per_launch = evals / max(1, a.steps * world)
-        achieved = leaves_per_launch * fps / net_s if net_s > 0 else 0.0
-        peak = PEAK_BF16 if a.dtype == "bf16" else PEAK_F32
-        out = {
-            "metric": "MCTS simulations/s", "value": sims / dt, "unit": "simulations/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"{a.games} concurrent self-play games/GPU x {a.sims} MCTS sims/move, "
-                                   f"THREADS_PER_MCTS {a.threads}, {a.blocks}-block 256-filter random-init net (BASELINE configs[1])",
-                       "games_per_gpu": a.games, "sims_per_move": a.sims, "mcts_threads": a.threads, "blocks": a.blocks,
-                       "parallelism": f"games sharded x{world}, no data-path collective; 1 all_gather of records"},
-            "simulations_per_s_p50_rank0": sorted(chunk_rates)[len(chunk_rates) // 2] if chunk_rates else None,
-            "self_play_games_per_s": games_rate["games_per_s"] if games_rate else games / dt,
-            "self_play_games_window": games_rate, "decisions_per_s": decisions / dt,
-            "net_evals_per_s": evals / dt, "mean_depth": levels / max(1, sims),
-            "games_finished": games, "records_gathered": int(allrecs.shape[0]), "errors": errors,
-            "nodes_dropped": dropped,
-            "roofline": {"bound": "mfma", "kernel": "k_tower_bf16 (one whole net forward of the G x T leaf slots: stem + 2B conv layers + both heads, one launch)"
-                         if a.dtype == "bf16" else "fp32 conv chain", "achieved": achieved / 1e12,
-                         "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "flop_per_launch": leaves_per_launch * fps, "leaves_per_launch": leaves_per_launch,
-                         "leaf_slots_per_launch": a.games * a.threads, "avg_launch_ms": prof["net_ms"],
-                         "tree_step_avg_ms": prof["tree_ms"], "timed_launches": prof["launches"],
-                         # HBM-side bytes per launch from rocprofv3 PMC (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction),
-                         # profiles/r01_final_pmc_fetch_write_g256_s100_t{1,2}_b20.txt — measured for exactly these configurations
-                         "traffic": {(256, 1, 20, "bf16"): (2 * 186413.07 + 56.0) * 1024,
-                                     (256, 2, 20, "bf16"): (2 * 186194.60 + 96.0) * 1024}.get(
-                                         (a.games, a.threads, a.blocks, a.dtype))},
-        }
-        # the HBM-side part of a simulation: node reads / backup writes per tree level, leaf record, prior and
-        # node write per evaluation, state + control block per game and pass.  One wavefront walks one game's tree, so
-        # this kernel is bound by dependent-access latency, not by bandwidth: the fraction below says how far from it.
-        lv, ev = levels / max(1, world), evals / max(1, world)
-        tree_bytes = lv * (640 + 64 + 12 + 4) + ev * (96 + 64 + 16 + 176 + 4 + 640 + 8) + a.steps * a.games * (64 + 128) * 2
-        tree_s = prof["tree_ms"] * 1e-3 * a.steps
-        out["tree_step"] = {"bound": "hbm", "kernel": "k_tree_step (select / expand / backup / decision for every game, one wavefront each)",
-                            "achieved": tree_bytes / tree_s / 1e9 if tree_s > 0 else 0.0, "peak": 8000.0, "unit": "GB/s",
-                            "frac": tree_bytes / tree_s / 8e12 if tree_s > 0 else 0.0,
-                            "bytes_per_simulation": tree_bytes / max(1.0, sims / max(1, world)), "avg_launch_ms": prof["tree_ms"],
-                            "note": "latency-bound pointer chasing (mean depth %.2f); 4-5 %% of the step" % (levels / max(1, sims))}
+        out = {"metric": "MCTS simulations/s", "value": head.pop("value"), "unit": "simulations/s", "n_gpus": world,
+               "steps": head.pop("steps"), "warmup": head.pop("warmup"), "ms_per_step": head.pop("ms_per_step"),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic"}
+        out.update(head)
+        if extras:
+            out["extra_configs"] = extras
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.blocks, a.sims, a.threads)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
-    eng.close()
 
 
 if __name__ == "__main__":

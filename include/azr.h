@@ -71,9 +71,12 @@ typedef struct azr_engine azr_engine;
 /* Settings() defaults (src/settings.h:22-81) */
 void azr_default_settings(azr_settings* s);
 
+/* On failure *out is NULL, nothing stays allocated and azr_last_error(NULL) holds the calling thread's reason.
+ * AZR_E_INVALID_ARGUMENT also for a node pool (node_capacity, or the default 16 * (mcts_simulations + 1)) above the
+ * 65534 nodes per game a 16-bit node index addresses. */
 int azr_engine_create(const azr_settings* s, azr_engine** out);
 int azr_engine_destroy(azr_engine* h);
-const char* azr_last_error(const azr_engine* h);
+const char* azr_last_error(const azr_engine* h);   /* h == NULL: the last failed azr_engine_create of this thread */
 int azr_engine_games(const azr_engine* h);
 
 /* ---- game rules: `class State` + UtilityNN (state/state.cpp, alphazero_moves.cpp) -------------------- */
@@ -143,6 +146,10 @@ int azr_mcts_pick(azr_engine* h, int sample, uint8_t* moves_host);
 /* ---- device-resident self-play (trainer move loop, alphazero_trainer.cpp:80-119) --------------------------- */
 /* (Re)start all G games: game g plays seeds base_seed + g, then base_seed + G + g, ... */
 int azr_selfplay_start(azr_engine* h, uint32_t base_seed);
+/* The trainer's own loop bound (Counter::hasNext over TRAIN_ITERATION_GAMES, alphazero_trainer.cpp:83): start exactly
+ * `games` games — seeds base_seed .. base_seed + games - 1, handed to whichever slot is free next — and play every one
+ * of them to its end; slots idle once no game is left to start.  Done when games_finished + errors == games. */
+int azr_selfplay_start_games(azr_engine* h, uint32_t base_seed, uint64_t games);
 /* Run `passes` passes of the hot path: every pass = one tree step (backup/expand + select to the next leaf,
  * decisions, moves, game restarts — all on device) + one batched net evaluation of the G leaves. */
 int azr_selfplay_run(azr_engine* h, int passes);
@@ -155,10 +162,17 @@ typedef struct azr_counters {
     uint64_t samples;       /* records produced */
     uint64_t nodes_dropped; /* expansions skipped because the node pool was full (should be 0) */
     uint64_t errors;        /* games stopped on a rules error (should be 0) */
+    uint64_t records_dropped; /* records lost because a game outgrew sample_capacity or the ring was full (should be 0;
+                                 `samples` counts them too) */
 } azr_counters;
 int azr_selfplay_counters(azr_engine* h, azr_counters* out);
-/* finished games' records, z filled (NNTrainDataStorage::updateValues, alphazero_nn_data.cpp:51-65) */
+/* finished games' records, z filled (NNTrainDataStorage::updateValues, alphazero_nn_data.cpp:51-65).  Copies the first
+ * min(available, cap_records) records; the others STAY buffered for the next call (drain in a loop until *n_out <
+ * cap_records).  rec265_host == NULL discards everything buffered. */
 int azr_samples_drain(azr_engine* h, void* rec265_host, size_t cap_records, size_t* n_out);
+/* the same copy to DEVICE memory of this GPU (e.g. a collective's send buffer), on the engine's own stream, without
+ * removing anything: min(available, cap_records) records */
+int azr_samples_copy_device(azr_engine* h, void* rec265_device, size_t cap_records, size_t* n_out);
 /* device-side view for RCCL gathers: pointer to the packed record ring and its count; valid until the next
  * azr_selfplay_run / azr_samples_drain */
 int azr_samples_device_view(azr_engine* h, void** dev_ptr_out, size_t* n_out);

@@ -2,6 +2,8 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  first: torch bundles its own libamdhip64 (same soname as /opt/rocm's); loaded before the C-ABI
+#              library, both bind to ONE HIP runtime (alphazero-risk_amd/shard.py:_one_hip_runtime)
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 

@@ -1,5 +1,5 @@
 """the native optimiser step (azr_nn_train*, csrc/azr_train.hip) against the same graph in PyTorch fp32 on
-the CPU (alphazero-risk_amd/train.py::AzrNet, itself checked against the oracle's forward pass in tests/test_train.py).
+the CPU (tests/torch_train_ref.py::AzrNet, itself checked against the oracle's forward pass in tests/test_train.py).
 "parity unpinned": the reference's step is a TensorFlow session (absent here); what is pinned is build_graph.py's
 arithmetic — losses, batch-statistics BN incl. the stem's axis-1 BN, gradients, L2, TF-formula Adam, moving averages —
 and the reference's epoch loop (libstdc++ std::shuffle on minstd_rand0, remainder dropped, epoch-average losses).
@@ -16,7 +16,7 @@ import azr_testlib as T
 from gpu_common import ROOT, pkg
 
 pytestmark = pytest.mark.gpu
-train = importlib.import_module("alphazero-risk_amd.train")
+import torch_train_ref as train
 
 
 def records(n, seed=0):

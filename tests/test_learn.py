@@ -20,7 +20,7 @@ def learn_mod():
 
 
 def test_invert_players_matches_oracle(orc):
-    L = learn_mod()
+    import host_arena as L
     g = np.load(os.path.join(T.GOLDEN, "rules_games.npz"))
     states = g["states"][::13][:200].copy()
     got = L.invert_players(states)
@@ -54,14 +54,13 @@ def test_trim_and_acceptance_rules():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("trainer,arena", [("native", "device"), ("native", "host")])
-def test_one_learn_iteration_end_to_end(tmp_path, trainer, arena):
+def test_one_learn_iteration_end_to_end(tmp_path):
     L = learn_mod()
     cwd = os.getcwd()
     os.chdir(tmp_path)
     try:
         a = argparse.Namespace(ti=1, tg=8, mcts=6, gpu_games=8, blocks=1, e=2, bs=64, cg=4, ct=0.0, s=1024 * 512,
-                               seed=77, dtype="bf16", device=0, trainer=trainer, arena=arena, include_compare_samples=1)
+                               seed=77, dtype="bf16", device=0, include_compare_samples=1)
         out = L.learn(a, log=lambda *_: None)
     finally:
         os.chdir(cwd)
@@ -81,16 +80,18 @@ def test_one_learn_iteration_end_to_end(tmp_path, trainer, arena):
 
 
 @pytest.mark.gpu
-def test_learn_cli_with_the_pytorch_cross_check_step(tmp_path):
-    """`--trainer torch` (train.py, PyTorch-ROCm autograd) in a fresh process: torch's HIP runtime must come up before the
-    C-ABI library's, which a test process that already created engines cannot guarantee"""
-    import subprocess
-    import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "alphazero-risk_amd", "learn.py"), "--ti", "1", "--tg", "8", "--mcts", "6",
-                        "--gpu-games", "8", "--blocks", "1", "-e", "1", "--bs", "64", "--cg", "4", "--ct", "0", "--trainer", "torch"],
-                       cwd=tmp_path, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    assert "Loss Policy / Value" in r.stdout and "Model improved" in r.stdout
+def test_host_stepped_arena_through_the_player_seam():
+    """the batched Player seam of the binding (takeTurns = trim, simulate, argmax, makeMove until the turn passes) plays
+    whole mirrored game pairs between two engines (tests/host_arena.py; the product's arena is the device one)"""
+    import host_arena
+    P = importlib.import_module("alphazero-risk_amd")
+    a = P.Engine(4, blocks=1, sims=6, dtype=P.NET_BF16, max_game_rounds=20)
+    b = P.Engine(4, blocks=1, sims=6, dtype=P.NET_BF16, max_game_rounds=20)
+    a.init_random(1)
+    b.init_random(2)
+    r = host_arena.arena_two_nets(a, b, 8, True, 5)
+    assert r["count"] == 8 and r["draw"] + r["win"][0] + r["win"][1] == 8
+    a.close(); b.close()
 
 
 @pytest.mark.gpu

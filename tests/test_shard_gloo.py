@@ -70,3 +70,30 @@ def test_split_count_covers_the_total():
         for world in (1, 2, 3, 8):
             parts = [shard.split_count(total, world, r) for r in range(world)]
             assert sum(parts) == total and max(parts) - min(parts) <= 1 and parts == sorted(parts, reverse=True)
+
+
+def test_selfplay_seed_streams_never_collide():
+    """the (iteration, rank) seed sets must be disjoint.  Every rank's stream is base + rank * 2^24 +
+    (games it has started so far); with azr_selfplay_start_games game i of a batch plays seed + i."""
+    import importlib
+    shard = importlib.import_module("alphazero-risk_amd.shard")
+    world = 8
+    for tg in (1000, 256 * 8, 2048 * 8 + 5):
+        started = [0] * world
+        ranges = []
+        for it in range(1000):
+            for r in range(world):
+                n = shard.split_count(tg, world, r)
+                s0 = shard.selfplay_seed(20260001, r, started[r])
+                started[r] += n
+                ranges.append((s0, s0 + n))
+                if started[r] + n >= shard.SEED_STRIDE:
+                    break
+        ranges.sort()
+        for (a0, a1), (b0, b1) in zip(ranges, ranges[1:]):
+            assert a1 <= b0, (tg, (a0, a1), (b0, b1))
+        # minstd_rand0 seeding folds seeds mod 2^31 - 1: the ranges stay below it
+        assert ranges[-1][1] < 2**31 - 1
+    import pytest
+    with pytest.raises(ValueError):
+        shard.selfplay_seed(1, 0, shard.SEED_STRIDE)

@@ -1,4 +1,4 @@
-"""SURVEY §8 f-2 (provisional train step, alphazero-risk_amd/train.py): the PyTorch graph bound to the AZRW vector
+"""SURVEY §8 f-2 (provisional train step, tests/torch_train_ref.py): the PyTorch graph bound to the AZRW vector
 reproduces the oracle's forward pass; losses, L2 term, Adam step and BN running statistics follow build_graph.py.
 "parity unpinned" (TensorFlow absent): tolerances stated per test.  CPU."""
 import ctypes as C
@@ -11,7 +11,7 @@ import torch
 import azr_testlib as T
 from gpu_common import ROOT  # noqa: F401  (puts the repo root on sys.path)
 
-train = importlib.import_module("alphazero-risk_amd.train")
+import torch_train_ref as train
 
 
 def inputs(n):

@@ -4,7 +4,7 @@ The product's optimiser step is `azr_nn_train` (csrc/azr_train.hip: hand-written
 the AZRW vector).  This module is the same graph — python/src/build_graph.py:54-103, driven by AlphaZeroNN::train,
 neural_network/alphazero_nn.cpp:351-410 — in PyTorch autograd over the same AZRW flat parameter vector.  It is what the
 native step is tested against (tests/test_gpu_train.py, float64 on the CPU), the timing yard-stick of
-tools/train_bench.py (PyTorch-ROCm / MIOpen), and `learn.py --trainer torch`.  Inference, search and self-play never
+tools/train_bench.py (PyTorch-ROCm / MIOpen).the float64 reference of tests/test_gpu_train.py.  Inference, search and self-play never
 touch it.  Parity: "unpinned" (no TensorFlow here); its forward pass is checked against the oracle's fp32 restatement
 and its update rule against a NumPy Adam in tests/test_train.py.
 

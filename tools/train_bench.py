@@ -50,7 +50,8 @@ def main():
 
 def torch_time(a, eng, rec):
     import torch
-    T = importlib.import_module("alphazero-risk_amd.train")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch_train_ref as T
     tr = T.Trainer(a.blocks, eng.get_weights(), device="cuda:0", batch_size=a.bs, seed=0)
     tr.train(rec[:a.bs], 1)
     torch.cuda.synchronize()
