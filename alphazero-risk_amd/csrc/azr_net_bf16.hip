@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "azr_internal.hpp"
+#include "azr_bf16_common.hpp"
 
 using namespace azr;
 
@@ -35,59 +36,8 @@ using namespace azr;
         }                                                                                       \
     } while (0)
 
-namespace azr {
-void launch_heads_bf16(hipStream_t st, int n, const uint16_t* X, const float* hp, float* pi, float* v);
-const float* net_head_params(azr_engine* h);
-const float* net_fold(azr_engine* h);
-}  // namespace azr
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(8))) short s16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
-constexpr int ROWB = 544;                 // LDS bytes per activation row: 256 bf16 + 32 B pad: 16-B slot = (2*row + kgroup) mod 16 -> ds_read_b128 lane groups conflict-free
-constexpr int FROWB = 32;                 // LDS bytes per stem-feature row: 16 bf16 (13 planes + 3 zero)
-constexpr int KS_PER_TAP = 8;             // 256 input channels / 32 per MFMA
-constexpr int STEM_KS = 5;                // 9 taps x 16 channels = 144 -> 5 k-steps of 32 (last half zero)
-constexpr size_t FRAGS_PER_KSTEP = 16;    // 8 waves x 2 n-tiles, 64 lanes x 16 B each
-constexpr size_t TOWER_LAYER_HALFS = (size_t)9 * KS_PER_TAP * FRAGS_PER_KSTEP * 64 * 8;  // = 2304 * 256
-constexpr size_t STEM_HALFS = (size_t)STEM_KS * FRAGS_PER_KSTEP * 64 * 8;
-
-__host__ __device__ inline uint16_t f2bf(float f)
-{
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-__device__ __forceinline__ uint16_t bf_rne(float f)
-{
-    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32, round-to-nearest-even
-    return __builtin_bit_cast(uint16_t, b);
-}
-__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
-
-// setInStateTensor (alphazero_nn.cpp:31-67) for one cell/plane, from the 88-byte NNInputData image in LDS
-__device__ __forceinline__ float plane_value(const uint8_t* in88, int pos, int c)
-{
-    const uint32_t b = in88[pos];
-    const int army = b & 63, owner = b >> 6, cur = in88[42], enemy = cur == 0 ? 1 : 0;
-    const float fa = (float)army / 32.0f;
-    const float* f = reinterpret_cast<const float*>(in88 + 48);
-    switch (c) {
-    case 0: return owner == cur ? fa : 0.0f;
-    case 1: return owner == enemy ? fa : 0.0f;
-    case 2: return owner == 2 ? fa : 0.0f;
-    case 3: return f[9];
-    case 4: return f[0];
-    case 5: return f[1];
-    case 6: return f[2];
-    default: return c < 13 ? f[3 + (c - 7)] : 0.0f;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Row order inside a workgroup.  A 3x3 SAME conv on the 7x6 board has 304 valid (cell, tap) pairs of 378: a fifth of a
 // dense tiling's MFMAs multiply the zero row.  Cells are therefore ordered by border class so that whole 16-row MFMA
@@ -162,8 +112,6 @@ struct Geo {
     static constexpr int LDS_BYTES = ROWCELL_OFF + 2 * MT * 16;
 };
 
-constexpr size_t KSTRIDE = FRAGS_PER_KSTEP * 64;  // s16x8 units between consecutive k-steps
-constexpr int MAX_RING = 16;
 
 // ---------------------------------------------------------------------------------------------------------------
 // Wave tiling: the 16 column tiles (16 channels each) of N = 256 are split over WAVES = 16 / NT waves, NT tiles per
@@ -171,7 +119,6 @@ constexpr int MAX_RING = 16;
 // fragment read from LDS then feeds 4 MFMAs instead of 2, halving the LDS traffic that co-limits the 8-wave shape.
 // The packed weight stream is identical for both (fragment index = column tile).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr size_t KBYTES = KSTRIDE * 16;  // bytes per k-step of packed weights (all 16 column tiles)
 
 // ring depth in taps (8 k-steps each)
 template <int NB, int NT> struct RingTaps { static constexpr int value = (NB == 1) ? 2 : 1; };
@@ -593,12 +540,7 @@ __global__ __launch_bounds__(1024 / NT, NT == 2 ? 2 : 1) void k_tower_bf16(const
     tower_body<NB, NT>(lds, bid * NB, in88, in_stride, n, stem_wp, tower_wp, fold, blocks, hp, pi_out, v_out, diag, slot_map);
 }
 
-struct Bf16Net {
-    uint16_t* stem_wp = nullptr;
-    uint16_t* tower_wp = nullptr;
-    unsigned long long* diag = nullptr;  // set only by azr_debug_tower_clock
-};
-Bf16Net* bn(azr_engine* h) { return reinterpret_cast<Bf16Net*>(h->net.bf16ctx); }
+Bf16Net* bn(azr_engine* h) { return bf16net(h); }
 }  // namespace
 
 namespace azr {
@@ -617,7 +559,10 @@ int net_bf16_alloc(azr_engine* h)
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<1>::LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<2>::LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<3>::LDS_BYTES));
-    return AZR_OK;
+    // tuning switches are read ONCE, here (never in the launch path)
+    x->nt = getenv("AZR_TOWER_NT") && atoi(getenv("AZR_TOWER_NT")) == 4 ? 4 : 2;
+    x->sb_mode = getenv("AZR_TOWER_SB") ? atoi(getenv("AZR_TOWER_SB")) : 1;
+    return tower_sb_init(h);
 }
 
 void net_bf16_free(azr_engine* h)
@@ -676,8 +621,7 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
     if (h->pe_tower0) hipEventRecord(h->pe_tower0, st);
     // boards per workgroup: fill the 256 CUs first, then grow the M tile.  Wave tiling: 8 waves x 32 channels by
     // default; AZR_TOWER_NT=4 selects the 4-wave x 64-channel shape (measured equal at NB = 1, 2; slower at NB = 3).
-    static const int nt_env = getenv("AZR_TOWER_NT") ? atoi(getenv("AZR_TOWER_NT")) : 0;
-    const int NT = nt_env == 4 ? 4 : 2;
+    const int NT = x->nt;
 #define LAUNCH_TOWER(NBV, NTV)                                                                                      \
     hipLaunchKernelGGL((k_tower_bf16<NBV, NTV>), dim3(wgs), dim3(1024 / NTV), Geo<NBV>::LDS_BYTES,                 \
                        st, d_in88, in_stride, n, x->stem_wp, x->tower_wp, fold, B, net_head_params(h), d_pi, d_v, x->diag, n_full, d_map)
@@ -688,7 +632,24 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
     if (nb == 0) { nb = 1; wgs = n_full = n; }          // fewer boards than CUs: one each
     else if (n_full == 0) n_full = W;                  // exact multiple: all workgroups carry nb
     else nb += 1;
-    if (getenv("AZR_TOWER_NOMIX")) { nb = n <= 256 ? 1 : n <= 512 ? 2 : 3; wgs = n_full = (n + nb - 1) / nb; }
+    // 4 boards per workgroup in one LDS image (azr_tower_sb.hip) when that needs fewer passes over the weight stream:
+    // sb_mode 0 = never, 1 = when it is the faster plan, 2 = whenever the batch has 4 boards per CU or more
+    if ((x->sb_mode == 1 && n >= 1024) || (x->sb_mode == 2 && n >= 4)) {
+        const int wgs4 = (n + 3) / 4, rounds4 = (wgs4 + 255) / 256;
+        // measured launch times per 256-workgroup round, ms: 1 / 2 / 3 boards 0.48 / 0.75 / 0.97 (round 1), 4 boards: T4
+        static const float t[4] = {0.0f, 0.48f, 0.75f, 0.97f};
+        const float T4 = 1.15f;
+        float old_ms = 0.0f;
+        {   // the mixed launch above: every CU slot runs `rounds` workgroups, n_full of them with nb boards
+            const int big = n_full, small = wgs - n_full;   // workgroups of nb and nb - 1 boards
+            old_ms = ((float)big * t[nb] + (float)small * t[nb > 1 ? nb - 1 : 1]) / 256.0f;
+        }
+        if (x->sb_mode == 2 || rounds4 * T4 < old_ms) {
+            int rc = tower_sb_launch(h, 4, wgs4, d_in88, in_stride, n, d_pi, d_v, d_map, st);
+            if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
+            return rc;
+        }
+    }
     if (nb == 1) { if (NT == 2) LAUNCH_TOWER(1, 2); else LAUNCH_TOWER(1, 4); }
     else if (nb == 2) { if (NT == 2) LAUNCH_TOWER(2, 2); else LAUNCH_TOWER(2, 4); }
     else { if (NT == 2) LAUNCH_TOWER(3, 2); else LAUNCH_TOWER(3, 4); }

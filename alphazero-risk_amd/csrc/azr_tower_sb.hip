@@ -1,0 +1,394 @@
+// azr_tower_sb.hip — k_tower_sb4: the whole policy/value net (python/src/build_graph.py:63-90) for FOUR boards per workgroup
+// with ONE LDS activation buffer (gfx950).
+//
+// Why a second tower kernel.  k_tower_bf16 (azr_net_bf16.hip) keeps two ping-pong activation images in LDS, which caps a
+// workgroup at 3 boards (M = 128 GEMM rows) — and every workgroup streams the whole 47 MB of packed weights once per
+// launch from its XCD's L2.  At 1..2 boards per CU that stream (16 KB per 32-deep k-step per CU) runs at the practical
+// L2 -> CU rate (~65 GB/s per CU) and the matrix pipes wait for it.  The only way to need fewer weight bytes per board
+// is more boards per CU.  Here a workgroup owns 4 boards (168 cells, 11 MFMA row tiles) in a SINGLE LDS image:
+//   * a layer's whole output lives in accumulator registers until the layer's last k-step (it always did); the image is
+//     overwritten in place between two barriers (all waves done reading | epilogue stores | all stores visible);
+//   * the residual input of a block — the values this wave itself stored two layers earlier — stays packed (bf16) in
+//     registers instead of in a second image: 88 registers per lane;
+//   * 4 waves (one per SIMD, up to 512 registers each) split the 256 output channels, 64 (four 16-wide tiles) each, so an
+//     activation fragment read from LDS feeds 4 MFMAs: LDS fragment traffic per MFMA is half that of the 8-wave tiles;
+//   * per k-step a wave issues, tile by tile, [4 MFMAs | 1 ds_read_b128 of that tile's NEXT k-step fragment], then the 4
+//     buffer loads that refill the weight-ring slot just consumed (ring = 4 k-steps ahead, never drained; the packed
+//     stream of all layers is contiguous, exactly as for k_tower_bf16 — both kernels read the same packed weights);
+//   * the layer loop is rolled (conv1 and conv2 of a block share the code; only the epilogue looks at the parity) and a
+//     layer's 72 k-steps are fully unrolled with compile-time skip masks: ~40 KB of straight-line code, inside the
+//     64 KB instruction cache.
+// Row order (border classes, see row_of4): 15 of the 99 (tile, tap) pairs are entirely out of board and are skipped.
+// Arithmetic is the k_tower_bf16 arithmetic — same k order, same fp32 epilogue, same RNE points — so results are
+// bit-identical across tile shapes (tests/test_gpu_net.py checks it).
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+
+#include "azr_internal.hpp"
+#include "azr_bf16_common.hpp"
+
+using namespace azr;
+
+#define HIPCHK(h, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (void)hipGetLastError(); /* the runtime's last-error slot is sticky: clear it */    \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
+            return AZR_E_HIP;                                                                   \
+        }                                                                                       \
+    } while (0)
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+namespace {
+constexpr int NB = 4;                  // boards per workgroup
+constexpr int ROWS = 42 * NB;          // 168 board cells
+constexpr int MT = 11;                 // 16-row MFMA tiles (176 rows, 8 pad rows)
+constexpr int ZR = MT * 16;            // index of the shared zero row
+constexpr int NT = 4;                  // 16-channel column tiles per wave (4 waves x 64 channels)
+constexpr int WAVES = 4, THREADS = 256;
+constexpr int RING = 4;                // weight ring depth in k-steps
+// LDS map
+constexpr int BUF = (ZR + 1) * ROWB;                 // the activation image incl. its zero row            96 288 B
+constexpr int FEAT_OFF = BUF;                        // stem features [(ZR + 1)][16 bf16]                    5 664 B
+constexpr int HEAD_OFF = FEAT_OFF + (ZR + 1) * FROWB;  // heads scratch: NB x (128 + 256 + 64) floats       7 168 B
+constexpr int IN88_OFF = HEAD_OFF + NB * 448 * 4;    // NB x 96 B NNInputData images
+constexpr int ROWOF_OFF = IN88_OFF + NB * 96;        // u8 [176]: cell (board * 42 + pos) -> row
+constexpr int TAPROW_OFF = ROWOF_OFF + 176;          // u8 [10][ZR]: source row of (tap, row); tap 9 = all zero row
+constexpr int ROWCELL_OFF = TAPROW_OFF + 10 * ZR;    // u16 [ZR]: row -> y | x << 4 | board << 8, 0xffff = pad row
+constexpr int LDS_BYTES = ROWCELL_OFF + 2 * ZR;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(BUF % 16 == 0 && FEAT_OFF % 16 == 0 && HEAD_OFF % 16 == 0 && TAPROW_OFF % 4 == 0 && ROWCELL_OFF % 2 == 0, "alignment");
+
+// Row order.  tile 0 = 16 cells with y = 0, tile 1 = 16 cells y = 6, tile 2 = 16 cells x = 0 (y = 1..5), tile 3 = 16 cells
+// x = 5, tile 4 = the other 8 cells y = 0 + the 8 pad rows, tile 5 = the other 8 cells y = 6 + 4 cells x = 0 + 4 cells
+// x = 5, tiles 6..10 = the 80 interior cells.  Taps that leave the board from a tile's edge are skipped for that tile.
+__device__ __forceinline__ int row_of4(int b, int pos)
+{
+    const int y = pos / 6, x = pos - y * 6;
+    if (y == 0) { const int q = b * 6 + x; return q < 16 ? q : 64 + (q - 16); }
+    if (y == 6) { const int q = b * 6 + x; return q < 16 ? 16 + q : 80 + (q - 16); }
+    if (x == 0) { const int q = b * 5 + (y - 1); return q < 16 ? 32 + q : 88 + (q - 16); }
+    if (x == 5) { const int q = b * 5 + (y - 1); return q < 16 ? 48 + q : 92 + (q - 16); }
+    return 96 + b * 20 + (y - 1) * 4 + (x - 1);
+}
+// bit mt set = tile mt has no in-board source cell under this tap (tap 9 = "no tap": everything skipped)
+__host__ __device__ constexpr uint32_t skip_mask4(int tap)
+{
+    if (tap > 8) return 0xffffffffu;
+    const int ty = tap / 3, tx = tap - 3 * ty;
+    return (ty == 0 ? 0x11u : ty == 2 ? 0x2u : 0u) | (tx == 0 ? 0x4u : tx == 2 ? 0x8u : 0u);
+}
+
+__device__ __forceinline__ s16x8 lds16(const uint8_t* p) { return *reinterpret_cast<const s16x8*>(p); }
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+
+// Layer epilogue for 4 consecutive channels of one board cell: folded BN (fp32 fma), optional shortcut add (the packed
+// bf16 block input), ReLU, round-to-nearest-even to bf16.  Packed forms: v_pk_fma_f32 / v_pk_add_f32 / v_cvt_pk_bf16_f32 /
+// v_pk_max_i16 — ReLU is applied to the ROUNDED value as a signed 16-bit max with 0 (rounding is monotonic and odd, so
+// relu(rne(v)) == rne(relu(v)); -0 becomes +0 like `v > 0 ? v : 0`).
+template <bool SHORTCUT>
+__device__ __forceinline__ uint2 bn_relu_pack(const f32x4& acc, const float4& s, const float4& h, const uint2& x)
+{
+    // (the two instantiations are kept apart on purpose: merged by the optimiser, the common fma of all 44 tiles is hoisted
+    //  above the parity branch and 176 intermediate values have to be parked)
+    f32x4 t = acc;
+    if (SHORTCUT) asm volatile("; epilogue with shortcut" : "+v"(t));
+    else asm volatile("; epilogue" : "+v"(t));
+    f32x2 lo = __builtin_elementwise_fma(f32x2{t[0], t[1]}, f32x2{s.x, s.y}, f32x2{h.x, h.y});
+    f32x2 hi = __builtin_elementwise_fma(f32x2{t[2], t[3]}, f32x2{s.z, s.w}, f32x2{h.z, h.w});
+    if (SHORTCUT) {
+        lo += f32x2{__uint_as_float(x.x << 16), __uint_as_float(x.x & 0xffff0000u)};
+        hi += f32x2{__uint_as_float(x.y << 16), __uint_as_float(x.y & 0xffff0000u)};
+    }
+    const s16x2 z = {0, 0};
+    const s16x2 a = __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(lo, bf16x2)), z);
+    const s16x2 b = __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(hi, bf16x2)), z);
+    return uint2{__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b)};
+}
+
+__global__ __launch_bounds__(THREADS, 1) void k_tower_sb4(const uint8_t* __restrict__ in88, int in_stride, int n,
+                                                          const uint16_t* __restrict__ stem_wp, const uint16_t* __restrict__ tower_wp,
+                                                          const float* __restrict__ fold, int blocks, const float* __restrict__ hp,
+                                                          float* __restrict__ pi_out, float* __restrict__ v_out,
+                                                          unsigned long long* __restrict__ diag, const int* __restrict__ slot_map)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t* bufX = lds;
+    uint8_t* bufF = lds + FEAT_OFF;
+    uint8_t* in_l = lds + IN88_OFF;
+    uint8_t* rowof = lds + ROWOF_OFF;
+    uint8_t* taprow = lds + TAPROW_OFF;
+    uint16_t* rowcell = reinterpret_cast<uint16_t*>(lds + ROWCELL_OFF);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;        // MFMA fragment coordinates: board cell (column) c of a tile, k-group g
+    const int board0 = blockIdx.x * NB;
+    if (diag && blockIdx.x == 0 && tid == 0) { diag[0] = __builtin_amdgcn_s_memtime(); diag[1] = __builtin_amdgcn_s_memrealtime(); }
+
+    // ---- weight ring: the first RING k-steps of layer 0 fly while the tables and the stem are built
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(tower_wp), (short)0, 0x7fffffff, 0x00020000);
+    const uint32_t loff = (uint32_t)((wave * NT) * 64 + lane) * 16u;   // this lane's fragment bytes inside a k-step block
+    uint32_t wk = 0;                                                     // byte offset of the current k-step (wave-uniform)
+    u32x4 bq[RING][NT];
+#pragma unroll
+    for (int ks = 0; ks < RING; ks++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) bq[ks][nt] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, loff + nt * 1024, ks * (int)KBYTES, 0);
+
+    // ---- stage the NNInputData images, build the row tables
+    for (int i = tid; i < NB * 96; i += THREADS) {
+        const int b = i / 96, o = i % 96;
+        const int slot = (board0 + b < n) ? (slot_map ? slot_map[board0 + b] : board0 + b) : 0;
+        in_l[i] = (board0 + b < n && o < 88) ? in88[(size_t)slot * in_stride + o] : (uint8_t)0;
+    }
+    for (int i = tid; i < ROWB / 4; i += THREADS) reinterpret_cast<uint32_t*>(bufX + ZR * ROWB)[i] = 0;
+    for (int i = tid; i < ZR; i += THREADS) rowcell[i] = 0xffffu;
+    __syncthreads();
+    for (int i = tid; i < ROWS; i += THREADS) {
+        const int b = i / 42, pos = i - b * 42, r = row_of4(b, pos);
+        rowof[i] = (uint8_t)r;
+        rowcell[r] = (uint16_t)((pos / 6) | ((pos % 6) << 4) | (b << 8));
+    }
+    __syncthreads();
+    for (int i = tid; i < 10 * ZR; i += THREADS) {   // source row of row r under tap t (pad rows and out-of-board taps: the zero row)
+        const int t = i / ZR, r = i - t * ZR;
+        const int ci = rowcell[r];
+        int src = ZR;
+        if (t < 9 && ci != 0xffff) {
+            const int y = (ci & 15) + t / 3 - 1, x = ((ci >> 4) & 15) + t % 3 - 1;
+            if ((unsigned)y < 7u && (unsigned)x < 6u) src = rowof[(ci >> 8) * 42 + y * 6 + x];
+        }
+        taprow[i] = (uint8_t)src;
+    }
+    // stem features: bufF as [ZR + 1][16] bf16 (row ZR = zero row); planes 13..15 are zero
+    for (int i = tid; i < (ZR + 1) * 16; i += THREADS) {
+        const int r = i >> 4, ch = i & 15;
+        float v = 0.0f;
+        const int ci = r < ZR ? rowcell[r] : 0xffff;
+        if (ci != 0xffff) v = plane_value(in_l + (ci >> 8) * 96, (ci & 15) * 6 + ((ci >> 4) & 15), ch);
+        reinterpret_cast<uint16_t*>(bufF)[i] = bf_rne(v);
+    }
+    __syncthreads();
+
+    f32x4 acc[MT][NT];
+    uint2 res[MT][NT];      // the block input of this wave's (cell, 4-channel) elements, packed bf16: the residual operand
+    const uint32_t eoff = (uint32_t)(c * ROWB + (wave * 64 + g * 4) * 2);   // epilogue store address of tile 0 / column tile 0
+    const bool pad4 = c >= 8;                                                // lanes of tile 4 that hold pad rows
+
+    // ---- stem: 3x3 conv 13 -> 256, two taps per 32-deep k-step (tap = 2*ks + (g >> 1), channels (g & 1)*8 ..), weights as
+    //      the MFMA "A" operand: D[channel][cell], a lane ends up with 4 consecutive channels of one board cell
+    {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[mt][nt] = f32x4{0, 0, 0, 0};
+        const s16x8* wp = reinterpret_cast<const s16x8*>(stem_wp) + (size_t)(wave * NT) * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < STEM_KS; ks++) {
+            const int tap = 2 * ks + (g >> 1);   // 0..9; tap 9 (second half of the last k-step) is the zero row
+            s16x8 b[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) b[nt] = wp[(size_t)ks * FRAGS_PER_KSTEP * 64 + nt * 64];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const int row = taprow[tap * ZR + mt * 16 + c];
+                const s16x8 av = lds16(bufF + row * FROWB + (g & 1) * 16);
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[nt]), __builtin_bit_cast(bf16x8, av), acc[mt][nt], 0, 0, 0);
+            }
+        }
+        // conv_bn over the board ROW (build_graph.py:68 axis=1) + ReLU
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const int ci = rowcell[mt * 16 + c];
+            const int y = ci == 0xffff ? 0 : (ci & 15);
+            const float sc = fold[y], sh = fold[7 + y];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                const uint2 o = bn_relu_pack<false>(acc[mt][nt], float4{sc, sc, sc, sc}, float4{sh, sh, sh, sh}, uint2{0, 0});
+                res[mt][nt] = o;
+                if (mt != 4 || !pad4) *reinterpret_cast<uint2*>(bufX + eoff + mt * 16 * ROWB + nt * 32) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- residual tower: 2B conv layers, activations resident in the one LDS image
+    const uint8_t* tr_c = taprow + c;           // this lane's column of the (tap, row) -> source-row table
+    const uint32_t g16 = (uint32_t)g * 16u;
+    const int layers = 2 * blocks;
+    for (int L = 0; L < layers; L++) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[mt][nt] = f32x4{0, 0, 0, 0};
+        uint32_t ap[MT];        // LDS byte address of this lane's fragment of tile mt at k-step 0 of the current tap
+        s16x8 a[MT];            // ... and the fragment of the k-step about to run
+        {
+            const uint32_t sk0 = skip_mask4(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                ap[mt] = (uint32_t)tr_c[mt * 16] * ROWB + g16;
+                if (!((sk0 >> mt) & 1u)) a[mt] = lds16(bufX + ap[mt]);
+            }
+        }
+        // this layer's folded BN (4 consecutive channels per lane and column tile)
+        float4 sc[NT], sh[NT];
+        {
+            const float* fs = fold + 14 + (size_t)L * 2 * NF + wave * 64 + g * 4;
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                sc[nt] = *reinterpret_cast<const float4*>(fs + nt * 16);
+                sh[nt] = *reinterpret_cast<const float4*>(fs + NF + nt * 16);
+            }
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {   // fully unrolled: skip masks are compile-time, no branch in the layer's main loop
+            const uint32_t sk = skip_mask4(tap), skn = skip_mask4(tap + 1);
+            uint32_t np[MT];
+#pragma unroll
+            for (int ks = 0; ks < KS_PER_TAP; ks++) {
+                if (ks == KS_PER_TAP - 3) {   // the next tap's source rows, a little before they are needed
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) np[mt] = (uint32_t)tr_c[(tap + 1) * ZR + mt * 16] * ROWB + g16;
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    if (!((sk >> mt) & 1u)) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; nt++)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[ks % RING][nt]),
+                                                                                  __builtin_bit_cast(bf16x8, a[mt]), acc[mt][nt], 0, 0, 0);
+                        if (ks < KS_PER_TAP - 1) a[mt] = lds16(bufX + ap[mt] + (ks + 1) * 64);
+                    }
+                    if (ks == KS_PER_TAP - 1) { if (!((skn >> mt) & 1u)) a[mt] = lds16(bufX + np[mt]); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // the ring slot just consumed is refilled RING k-steps ahead (also across layer boundaries)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+                    bq[ks % RING][nt] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, loff + nt * 1024, (int)(wk + RING * KBYTES), 0);
+                wk += (uint32_t)KBYTES;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) ap[mt] = np[mt];
+        }
+        __syncthreads();        // every wave has read the image for the last time
+        if (L & 1) {    // second conv of a block: + shortcut (the block's input, kept packed in registers), and this
+                        // output is the next block's input
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    const uint2 o = bn_relu_pack<true>(acc[mt][nt], sc[nt], sh[nt], res[mt][nt]);
+                    res[mt][nt] = o;
+                    if (mt != 4 || !pad4) *reinterpret_cast<uint2*>(bufX + eoff + mt * 16 * ROWB + nt * 32) = o;
+                }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    const uint2 o = bn_relu_pack<false>(acc[mt][nt], sc[nt], sh[nt], uint2{0, 0});
+                    if (mt != 4 || !pad4) *reinterpret_cast<uint2*>(bufX + eoff + mt * 16 * ROWB + nt * 32) = o;
+                }
+        }
+        __syncthreads();        // the new image is complete
+    }
+
+    if (diag && blockIdx.x == 0 && tid == 0) { diag[2] = __builtin_amdgcn_s_memtime(); diag[3] = __builtin_amdgcn_s_memrealtime(); }
+    // ---- both heads (build_graph.py:76-90; the arithmetic of k_tower_bf16's fused heads, same order)
+    {
+        const float* wpi = hp;              // [256][2]
+        const float* bnpi = wpi + NF * 2;   // g[2] b[2] m[2] v[2]
+        const float* wd = bnpi + 8;         // [84][43]
+        const float* bd = wd + 84 * 43;     // [43]
+        const float* wv = bd + 43;          // [256]
+        const float* bnv = wv + NF;         // g b m v
+        const float* w1 = bnv + 4;          // [42][256]
+        const float* b1 = w1 + 42 * 256;    // [256]
+        const float* w2 = b1 + 256;         // [256]
+        const float* b2 = w2 + 256;         // [1]
+        float* feat = reinterpret_cast<float*>(lds + HEAD_OFF);   // [NB][128]: 84 policy features, then 42 value features
+        float* hid = feat + NB * 128;                             // [NB][256]
+        float* logit = hid + NB * 256;                            // [NB][64]
+        for (int idx = tid; idx < NB * 126; idx += THREADS) {  // 42 cells x {pi0, pi1, v} per board
+            const int bb = idx / 126, t = idx % 126, pos = t / 3, ch = t % 3;
+            const uint16_t* x = reinterpret_cast<const uint16_t*>(bufX + rowof[bb * 42 + pos] * ROWB);
+            float sacc = 0.0f;
+            if (ch < 2) for (int ci = 0; ci < NF; ci++) sacc = fmaf(bf2f(x[ci]), wpi[ci * 2 + ch], sacc);
+            else for (int ci = 0; ci < NF; ci++) sacc = fmaf(bf2f(x[ci]), wv[ci], sacc);
+            const float* bnp = ch < 2 ? bnpi : bnv;
+            const int nc = ch < 2 ? 2 : 1, kk = ch < 2 ? ch : 0;
+            float y = (sacc - bnp[2 * nc + kk]) * (bnp[kk] / sqrtf(bnp[3 * nc + kk] + 1e-3f)) + bnp[nc + kk];
+            y = y > 0.0f ? y : 0.0f;
+            if (ch < 2) feat[bb * 128 + pos * 2 + ch] = y;  // NHWC flatten: (y*6+x)*2 + c
+            else feat[bb * 128 + 84 + pos] = y;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < NB * 43; idx += THREADS) {
+            const int bb = idx / 43, t = idx % 43;
+            float sacc = 0.0f;
+            for (int i = 0; i < 84; i++) sacc = fmaf(feat[bb * 128 + i], wd[i * 43 + t], sacc);
+            logit[bb * 64 + t] = sacc + bd[t];
+        }
+        for (int idx = tid; idx < NB * 256; idx += THREADS) {
+            const int bb = idx >> 8, t = idx & 255;
+            float sacc = 0.0f;
+            for (int i = 0; i < 42; i++) sacc = fmaf(feat[bb * 128 + 84 + i], w1[i * 256 + t], sacc);
+            sacc += b1[t];
+            hid[idx] = (sacc > 0.0f ? sacc : 0.0f) * w2[t];
+        }
+        __syncthreads();
+        // one wave per (board, head): softmax over the 43 logits / tanh of the 256-term value sum
+        for (int job = wave; job < NB * 2; job += WAVES) {
+            const int bb = job >> 1;
+            if (board0 + bb >= n) continue;
+            const int slot = slot_map ? slot_map[board0 + bb] : board0 + bb;
+            if ((job & 1) == 0) {
+                const float lv = lane < 43 ? logit[bb * 64 + lane] : -INFINITY;
+                float mx = lv;
+                for (int sft = 32; sft >= 1; sft >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sft));
+                const float e = lane < 43 ? expf(lv - mx) : 0.0f;
+                float se = e;
+                for (int sft = 32; sft >= 1; sft >>= 1) se += __shfl_xor(se, sft);
+                if (lane < 43) pi_out[(size_t)slot * PI_STRIDE + lane] = e / se;
+                if (lane == 43) pi_out[(size_t)slot * PI_STRIDE + 43] = 0.0f;
+            } else {
+                const float* hb = hid + bb * 256;
+                float sacc = hb[lane] + hb[lane + 64] + hb[lane + 128] + hb[lane + 192];
+                for (int sft = 32; sft >= 1; sft >>= 1) sacc += __shfl_xor(sacc, sft);
+                if (lane == 0) v_out[slot] = tanhf(sacc + b2[0]);
+            }
+        }
+    }
+}
+}  // namespace
+
+namespace azr {
+
+int tower_sb_init(azr_engine* h)
+{
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_sb4), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    return AZR_OK;
+}
+
+// `wgs` workgroups of 4 boards: boards [0, n) of the launch (the last workgroup may be partly filled)
+int tower_sb_launch(azr_engine* h, int nb, int wgs, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st)
+{
+    if (nb != NB || wgs * NB < n) { h->err = "tower_sb_launch: bad tiling"; return AZR_E_INVALID_ARGUMENT; }
+    Bf16Net* x = bf16net(h);
+    hipLaunchKernelGGL(k_tower_sb4, dim3(wgs), dim3(THREADS), LDS_BYTES, st, d_in88, in_stride, n, x->stem_wp, x->tower_wp, net_fold(h),
+                       h->net.blocks, net_head_params(h), d_pi, d_v, x->diag, d_map);
+    HIPCHK(h, hipGetLastError());
+    return AZR_OK;
+}
+
+}  // namespace azr

@@ -126,6 +126,28 @@ def test_bf16_tower_at_depth_matches_fp32_oracle(orc, n):
     eng.close()
 
 
+def test_tile_shapes_agree_bit_for_bit(monkeypatch):
+    """the 4-boards-per-workgroup single-buffer kernel (azr_tower_sb.hip) and the 1..3-board kernels compute the same
+    bits: same k order, same fp32 epilogue, same rounding points (AZR_TOWER_SB is read once, at engine creation)"""
+    P = pkg()
+    blocks, n = 20, 1024
+    g = np.unique(np.load(os.path.join(T.GOLDEN, "encode.npz"))["in88"], axis=0)
+    x = g[np.linspace(0, len(g) - 1, n).astype(int)].copy()
+    flat = T.make_net_flat(blocks, seed=3, perturb_bn=True)
+    out = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("AZR_TOWER_SB", mode)
+        eng = P.Engine(n, blocks=blocks, sims=1, dtype=P.NET_BF16, node_capacity=64)
+        eng.set_weights(flat)
+        out[mode] = eng.predict(x)
+        # a ragged batch (last workgroup partly filled) and a tiny one take the same values
+        p7, v7 = eng.predict(x[:1023])
+        assert (p7.view(np.uint32) == out[mode][0][:1023].view(np.uint32)).all() and (v7 == out[mode][1][:1023]).all()
+        eng.close()
+    assert (out["0"][0].view(np.uint32) == out["2"][0].view(np.uint32)).all()
+    assert (out["0"][1].view(np.uint32) == out["2"][1].view(np.uint32)).all()
+
+
 def test_bf16_search_picks_the_fp32_search_moves(orc):
     """north_star: "matching reference move selections on seeded boards".  The search is bit-exact GIVEN (pi, v)
     (test_gpu_mcts.py); this measures what the bf16 net changes: the same 96 seeded golden roots (all phases), B = 20,
