@@ -275,8 +275,7 @@ Engine::Engine(const Settings& s, int device, int g) : games(g)
     es.games = g;
     int rc = azr_engine_create(&es, &h);
     if (rc) {
-        std::string msg = h ? azr_last_error(h) : "azr_engine_create failed";
-        if (h) azr_engine_destroy(h);
+        std::string msg = azr_last_error(nullptr);   // *out is NULL on failure; the reason is kept per thread
         h = nullptr;
         throw std::runtime_error("engine: " + msg);
     }

@@ -56,6 +56,22 @@ def gr_str(gr):  # operator<<(GameResults) (game.cpp:227-235)
     return f"{gr['draw']}, {gr['win'][0]}/{gr['win_and_started'][0]}, {gr['win'][1]}/{gr['win_and_started'][1]}"
 
 
+def improvement_line(it, gr):
+    """one line of log/azr-improvement-log.txt (alphazero_trainer.cpp:163): iteration,GameResults"""
+    return f"{it},{gr_str(gr)}\n"
+
+
+def benchmark_line(it, random_gr, script_gr):
+    """one line of log/azr-benchmark-log.txt (alphazero_trainer.cpp:139): iteration,<vs Random>, <vs Script>"""
+    return f"{it},{gr_str(random_gr)}, {gr_str(script_gr)}\n"
+
+
+def nn_training_line(hist):
+    """one line of log/azr-nn-training-log.txt (LOG_NN_TRAINING): "policy loss, value loss, " per epoch, as `ostream <<
+    float` prints them (6 significant digits)"""
+    return "".join(f"{lp:g}, {lv:g}, " for lp, lv in hist) + "\n"
+
+
 def trim_old_examples(records, old_game_index, smin, smax):
     """NNTrainDataStorage::trimOldExamples (alphazero_nn_data.cpp:67-84)"""
     n = len(records)
@@ -65,6 +81,39 @@ def trim_old_examples(records, old_game_index, smin, smax):
         excess = min(old_game_index, n - smin)
         return records[excess:], old_game_index - excess
     return records, old_game_index
+
+
+def save_training_samples(path, records):
+    """NNTrainDataStorage::saveTrainingSamples (alphazero_nn_data.cpp:112-136): size_t count (8 bytes) + 265 bytes per record;
+    nothing is written for an empty buffer"""
+    records = np.ascontiguousarray(records, np.uint8).reshape(-1, 265)
+    if len(records) == 0:
+        return False
+    d = os.path.dirname(path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    with open(path, "wb") as f:
+        f.write(np.uint64(len(records)).tobytes())
+        f.write(records.tobytes())
+    return True
+
+
+def load_training_samples(path):
+    """NNTrainDataStorage::loadTrainingSamples (alphazero_nn_data.cpp:86-110).  The reference's writer emits an 8-byte
+    count while its reader consumes 4 bytes (so it mis-reads its own files by 4 bytes): both header widths are accepted
+    here, chosen by the file size, and the records come back intact.  A missing file is an empty buffer."""
+    if not os.path.exists(path):
+        return np.zeros((0, 265), np.uint8)
+    raw = np.fromfile(path, np.uint8)
+    if len(raw) >= 8:
+        n8 = int(raw[:8].view(np.uint64)[0])
+        if len(raw) == 8 + n8 * 265:
+            return raw[8:].reshape(n8, 265).copy()
+    if len(raw) >= 4:
+        n4 = int(raw[:4].view(np.int32)[0])
+        if n4 >= 0 and len(raw) == 4 + n4 * 265:
+            return raw[4:].reshape(n4, 265).copy()
+    raise ValueError(f"unrecognised sample file {path}: {len(raw)} bytes")
 
 
 def run_arena(eng, p1, p2, games, mirror, seed):
@@ -101,7 +150,7 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
     for e in (new, gen):
         e.load(latest)
     shuffle_state = a.seed % 2147483646 + 1   # raw minstd_rand0 state standing in for the reference's global RNG
-    records = np.zeros((0, 265), np.uint8)
+    records = load_training_samples("data/training_samples.bin")   # trainStorage.loadTrainingSamples(DEFAULT_SAMPLES)
     old_game_index = 0
     games_started = 0   # self-play games this rank has started in earlier iterations (its position in its seed stream)
     sink = "/dev/null" if rank else None
@@ -143,7 +192,7 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
         if rank == 0:   # AlphaZeroNNGroup::train: the first GPU trains (alphazero_gpu_cluster.cpp:221-231)
             hist, shuffle_state = new.train(records, a.e, batch_size=a.bs, rng_state=shuffle_state)
             hist = [h for h in hist if not np.isnan(h[0])]
-            nn_log.write("".join(f"{lp}, {lv}, " for lp, lv in hist) + "\n"); nn_log.flush()
+            nn_log.write(nn_training_line(hist)); nn_log.flush()
         if dist is not None:   # ... and the others receive its weights
             w = shard_mod.broadcast_flat(new.get_weights(), dist, src=0, device=cdev)
             if rank != 0:
@@ -166,7 +215,7 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
             if len(arecs):   # playGames(..., trainStorage): the compare games' samples join the replay buffer
                 records = np.concatenate([records, arecs])
                 log(f"New samples generated from compare games {len(arecs)}")
-            imp_log.write(f"{it},{gr_str(gr)}\n"); imp_log.flush()
+            imp_log.write(improvement_line(it, gr)); imp_log.flush()
             improved = is_model_improved(gr, a.ct)
             log(f"Compare games: {gr_str(gr)}   [{gr['count']} games in {time.time() - t_arena:.1f} s]")
         if improved:
@@ -181,7 +230,7 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
                           shard_mod.rank_base_seed(a.seed + 13, rank))
             if dist is not None:
                 r, s = reduce_results(r, dist, cdev), reduce_results(s, dist, cdev)
-            bench_log.write(f"{it},{gr_str(r)}, {gr_str(s)}\n"); bench_log.flush()
+            bench_log.write(benchmark_line(it, r, s)); bench_log.flush()
             log(f"Model benchmark: vs Random {r['win'][0]}/{r['count']}, vs Script {s['win'][0]}/{s['count']}   [{time.time() - t_bench:.1f} s]")
             old_game_index = max(len(records) - 1, 0)   # updateOldGamesIndex
         else:
@@ -190,10 +239,7 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
         summary.append(dict(iteration=it, samples=len(records), losses=hist, arena=gr, improved=improved))
     # saveTrainingSamples (reference writer layout: 8-byte count + 265-byte records)
     if rank == 0:
-        os.makedirs("data", exist_ok=True)
-        with open("data/training_samples.bin", "wb") as f:
-            f.write(np.uint64(len(records)).tobytes())
-            f.write(records.tobytes())
+        save_training_samples("data/training_samples.bin", records)
     gen.close(); new.close()
     return summary
 

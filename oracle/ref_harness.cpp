@@ -23,6 +23,7 @@
 #include <stdexcept>
 #include <sstream>
 #include <cstdio>
+#include <algorithm>
 
 #include "risk_game/player/alpha_zero/alphazero_moves.h"
 #include "risk_game/player/script/script_player.h"
@@ -273,6 +274,87 @@ int ref_landset_lands(int set, uint8_t* out12)
     int n = (int)sets[set]->lands.size();
     for (int i = 0; i < n; i++) out12[i] = Utility::li2i(sets[set]->lands[i]->landIndex);
     return n;
+}
+
+// ---- sample storage: saveTrainingSamples / loadTrainingSamples / trimOldExamples / extend / updateOldGamesIndex
+//      (neural_network/alphazero_nn_data.cpp:67-138,158-167).  Records cross this boundary in the 265-byte on-disk layout
+//      (i8 player | 88 B NNInputData | f32 z | f32 pi[43]).
+static void fill_storage(NNTrainDataStorage& st, const uint8_t* rec265, int n)
+{
+    for (int i = 0; i < n; i++, rec265 += 265) {
+        NNTrainData d;
+        d.playerIndex = (int8_t)rec265[0];
+        std::memcpy((void*)&d.in, rec265 + 1, sizeof(NNInputData));
+        std::memcpy(&d.out.value, rec265 + 89, 4);
+        d.out.policy.resize(TF_OUTPUT_POLICY_TENSOR_SIZE);
+        std::memcpy(d.out.policy.data(), rec265 + 93, 4 * TF_OUTPUT_POLICY_TENSOR_SIZE);
+        st.data.push_back(d);
+    }
+}
+static void dump_storage(const NNTrainDataStorage& st, uint8_t* rec265, int cap)
+{
+    for (int i = 0; i < (int)st.data.size() && i < cap; i++, rec265 += 265) {
+        const NNTrainData& d = st.data[i];
+        rec265[0] = (uint8_t)d.playerIndex;
+        std::memcpy(rec265 + 1, (const void*)&d.in, sizeof(NNInputData));
+        std::memcpy(rec265 + 89, &d.out.value, 4);
+        std::memset(rec265 + 93, 0, 4 * TF_OUTPUT_POLICY_TENSOR_SIZE);
+        std::memcpy(rec265 + 93, d.out.policy.data(), 4 * std::min<size_t>(d.out.policy.size(), TF_OUTPUT_POLICY_TENSOR_SIZE));
+    }
+}
+
+// the reference's WRITER on n records
+int ref_save_samples(const uint8_t* rec265, int n, const char* path)
+{
+    NNTrainDataStorage st;
+    fill_storage(st, rec265, n);
+    st.saveTrainingSamples(path);
+    return 0;
+}
+
+// the reference's READER: returns the number of records it believes the file holds (its 4-byte header read), and the
+// records as it parsed them
+int ref_load_samples(const char* path, uint8_t* rec265_out, int cap)
+{
+    NNTrainDataStorage st;
+    st.loadTrainingSamples(path);
+    dump_storage(st, rec265_out, cap);
+    return (int)st.data.size();
+}
+
+// trimOldExamples on n records (record i carries z = i as a marker) with the given oldGameIndex and storage limits;
+// returns the new count, *first_kept = marker of the first surviving record, *old_out = oldGameIndex afterwards
+int ref_trim_old_examples(int n, long old_game_index, int smin, int smax, int* first_kept, long* old_out)
+{
+    const int keep_min = SETTINGS.SAMPLES_STORAGE_MIN, keep_max = SETTINGS.SAMPLES_STORAGE_MAX;
+    SETTINGS.SAMPLES_STORAGE_MIN = smin;
+    SETTINGS.SAMPLES_STORAGE_MAX = smax;
+    NNTrainDataStorage st;
+    st.oldGameIndex = (size_t)old_game_index;
+    for (int i = 0; i < n; i++) {
+        NNTrainData d;
+        d.out.value = (float)i;
+        st.data.push_back(d);
+    }
+    st.trimOldExamples();
+    SETTINGS.SAMPLES_STORAGE_MIN = keep_min;
+    SETTINGS.SAMPLES_STORAGE_MAX = keep_max;
+    if (first_kept) *first_kept = st.data.empty() ? -1 : (int)st.data.front().out.value;
+    if (old_out) *old_out = (long)st.oldGameIndex;
+    return (int)st.data.size();
+}
+
+// extend (per-GPU storages appended in GPU order, alphazero_trainer.cpp:59-62) + updateOldGamesIndex
+int ref_extend(const uint8_t* a265, int na, const uint8_t* b265, int nb, uint8_t* out265, int cap, long* old_index_after_update)
+{
+    NNTrainDataStorage a, b;
+    fill_storage(a, a265, na);
+    fill_storage(b, b265, nb);
+    a.extend(b);
+    a.updateOldGamesIndex();
+    dump_storage(a, out265, cap);
+    if (old_index_after_update) *old_index_after_update = (long)a.oldGameIndex;
+    return (int)a.data.size();
 }
 
 } // extern "C"

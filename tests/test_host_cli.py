@@ -60,6 +60,10 @@ def test_learn_mode_generates_reference_format_samples(exe, tmp_path):
     for f in ("log/azr-improvement-log.txt", "log/azr-benchmark-log.txt", "log/azr-nn-training-log.txt",
               "checkpoints/best-checkpoint.bin", "checkpoints/checkpoint-iter-0.bin", "checkpoints/temp.bin"):
         assert os.path.getsize(tmp_path / f) > 0, f
+    from test_log_grammar import check   # the reference's own grammar (tests/golden/ref_logs) and log_chart.py's parsing
+    assert len(check("improvement", open(tmp_path / "log" / "azr-improvement-log.txt").read())) == 1
+    assert len(check("benchmark", open(tmp_path / "log" / "azr-benchmark-log.txt").read())) == 1
+    assert [len(r) for r in check("nn", open(tmp_path / "log" / "azr-nn-training-log.txt").read())] == [4]
     imp = open(tmp_path / "log" / "azr-improvement-log.txt").read().strip().split(",")
     assert imp[0] == "0" and len(imp) == 4
     nnl = open(tmp_path / "log" / "azr-nn-training-log.txt").read().strip().rstrip(",").split(",")
@@ -72,6 +76,8 @@ def test_learn_mode_generates_reference_format_samples(exe, tmp_path):
     z = rec[:, 89:93].copy().view(np.float32).reshape(n)
     assert np.allclose(pi.sum(1), 1, atol=1e-4) and set(np.unique(z)) <= {-1.0, 0.0, 1.0}
     assert os.path.exists(tmp_path / "checkpoints" / "latest-checkpoint.bin")  # missing checkpoint => init + save
+    # exactly TRAIN_ITERATION_GAMES self-play games were played to their end (Counter::hasNext, alphazero_trainer.cpp:83)
+    assert "Self-play: 6 games" in r.stdout
 
 
 @pytest.mark.gpu

@@ -70,6 +70,12 @@ def test_one_learn_iteration_end_to_end(tmp_path):
               "checkpoints/latest-checkpoint.bin", "checkpoints/best-checkpoint.bin", "checkpoints/checkpoint-iter-0.bin",
               "data/training_samples.bin"):
         assert os.path.getsize(tmp_path / f) > 0, f
+    from test_log_grammar import check   # the reference's own grammar (tests/golden/ref_logs) and log_chart.py's parsing
+    imp_rows = check("improvement", open(tmp_path / "log/azr-improvement-log.txt").read())
+    ben_rows = check("benchmark", open(tmp_path / "log/azr-benchmark-log.txt").read())
+    nn_rows = check("nn", open(tmp_path / "log/azr-nn-training-log.txt").read())
+    assert len(imp_rows) == 1 and imp_rows[0][0] == 0 and sum(imp_rows[0][1:3]) + imp_rows[0][4] == 4
+    assert len(ben_rows) == 1 and len(nn_rows) == 1 and len(nn_rows[0]) == 4          # 2 epochs x (policy, value)
     imp = open(tmp_path / "log/azr-improvement-log.txt").read().strip().split(",")
     assert imp[0] == "0" and len(imp) == 4          # iter, draws, new W/Wstart, old W/Wstart
     bench = open(tmp_path / "log/azr-benchmark-log.txt").read().strip()
