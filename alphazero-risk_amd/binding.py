@@ -45,6 +45,9 @@ class Counters(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)   # azr_allreduce_fn
+
+
 def lib_path():
     return os.path.join(CSRC, "libazr_hip.so")
 
@@ -62,10 +65,10 @@ EXPORTS = [
     "azr_engine_new_games", "azr_engine_set_states", "azr_engine_get_states", "azr_engine_set_rng", "azr_engine_get_rng",
     "azr_engine_valid_moves", "azr_engine_make_moves", "azr_engine_status", "azr_engine_encode",
     "azr_nn_param_count", "azr_nn_init_random", "azr_nn_set_weights", "azr_nn_get_weights", "azr_nn_load", "azr_nn_save",
-    "azr_nn_predict", "azr_nn_train", "azr_nn_train_batch", "azr_nn_train_grads", "azr_nn_train_reset", "azr_mcts_clear", "azr_mcts_trim", "azr_mcts_simulate", "azr_mcts_begin", "azr_mcts_leaves",
+    "azr_nn_predict", "azr_nn_train", "azr_nn_train_dp", "azr_nn_train_batch", "azr_nn_train_grads", "azr_nn_train_reset", "azr_mcts_clear", "azr_mcts_trim", "azr_mcts_simulate", "azr_mcts_begin", "azr_mcts_leaves",
     "azr_mcts_apply", "azr_mcts_root_stats", "azr_mcts_policy", "azr_mcts_pick", "azr_selfplay_start", "azr_selfplay_start_games",
     "azr_selfplay_run", "azr_selfplay_counters", "azr_samples_drain", "azr_samples_device_view", "azr_samples_copy_device", "azr_profile_last_run",
-    "azr_device_synchronize", "azr_arena_start", "azr_arena_run", "azr_arena_results", "azr_arena_log",
+    "azr_device_synchronize", "azr_debug_tower_clock", "azr_debug_tower_trace", "azr_arena_start", "azr_arena_run", "azr_arena_results", "azr_arena_log",
     "azr_arena_set_opponent_net", "azr_arena_collect_samples",
 ]
 
@@ -95,6 +98,8 @@ def load_library():
         L.azr_nn_save.argtypes = [C.c_void_p, C.c_char_p]
         L.azr_nn_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.azr_nn_train.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.azr_nn_train_dp.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]
         L.azr_nn_train_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.azr_nn_train_grads.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.azr_nn_train_reset.argtypes = [C.c_void_p]
@@ -260,6 +265,31 @@ class Engine:
         st = np.array([rng_state if rng_state is not None else 1], np.uint32)
         self._chk(self.L.azr_nn_train(self.h, _p(r), len(r), epochs, batch_size, _p(st) if rng_state is not None else None,
                                       _p(lp), _p(lv)))
+        return [(float(lp[e]), float(lv[e])) for e in range(epochs)], int(st[0])
+
+    def train_dp(self, rec265, epochs, allreduce, rank, world, batch_size=512, rng_state=None):
+        """azr_nn_train_dp: this rank's share of a data-parallel AlphaZeroNNId::train.  allreduce(device_ptr, count, dtype)
+        sums a device buffer over the ranks in place (dtype 0 = float32, 1 = float64); see shard.make_allreduce."""
+        r = np.ascontiguousarray(rec265, np.uint8).reshape(-1, 265)
+        lp = np.zeros(max(epochs, 1), np.float32)
+        lv = np.zeros(max(epochs, 1), np.float32)
+        st = np.array([rng_state if rng_state is not None else 1], np.uint32)
+
+        def cb(ctx, ptr, count, dtype):
+            try:
+                allreduce(ptr, count, dtype)
+                return 0
+            except Exception as e:   # never let an exception cross the C frame
+                self._dp_error = e
+                return 1
+
+        fn = ALLREDUCE_FN(cb)
+        self._dp_error = None
+        rc = self.L.azr_nn_train_dp(self.h, _p(r), len(r), epochs, batch_size, _p(st) if rng_state is not None else None, rank, world,
+                                    fn, None, _p(lp), _p(lv))
+        if rc and self._dp_error is not None:
+            raise self._dp_error
+        self._chk(rc)
         return [(float(lp[e]), float(lv[e])) for e in range(epochs)], int(st[0])
 
     def train_batch(self, rec265):

@@ -549,7 +549,7 @@ __global__ void t_gather(const uint8_t* __restrict__ rec, const int* __restrict_
                          uint8_t* __restrict__ in88, float* __restrict__ pit, float* __restrict__ zt)
 {
     const int b = blockIdx.x, t = threadIdx.x;
-    const uint8_t* r = rec + (size_t)perm[cur[0] + b] * 265;
+    const uint8_t* r = rec + (size_t)perm[cur[0] + cur[2] + b] * 265;   // cur[2] = this rank's offset inside the global minibatch
     for (int i = t; i < 88; i += blockDim.x) in88[b * 88 + i] = r[1 + i];
     for (int i = t; i < 44; i += blockDim.x) {
         float f;
@@ -825,9 +825,22 @@ __global__ __launch_bounds__(1024) void t_bn_bwd_stats(const float* __restrict__
     }
 }
 
-// backward stage 2: d(beta) = sum dz, d(gamma) = sum dz * xhat -> gradient vector; sums[0|1][ch] kept for stage 3
+// data-parallel step: this rank's per-block partials -> one [K][256] slab of doubles, which the ranks then all-reduce; the
+// finalize kernels read the reduced slab as "R = 1 block of partials"
+__global__ __launch_bounds__(256) void t_parts_sum(const double* __restrict__ part, int R, int K, double* __restrict__ red)
+{
+    const int c = threadIdx.x, k = blockIdx.x;
+    double s = 0.0;
+    for (int b = 0; b < R; b++) s += part[((size_t)b * K + k) * NF + c];
+    red[(size_t)k * NF + c] = s;
+}
+
+// backward stage 2: d(beta) = sum dz, d(gamma) = sum dz * xhat -> gradient vector; sums[0|1][ch] kept for stage 3.
+// gscale = 1 / world in a data-parallel step (the sums are already global; the closing all-reduce of the gradient vector
+// adds the `world` copies up again)
 template <bool STEM>
-__global__ __launch_bounds__(1024) void t_bn_bwd_finalize(const double* __restrict__ part, int R, float* __restrict__ gbn, float* __restrict__ sums)
+__global__ __launch_bounds__(1024) void t_bn_bwd_finalize(const double* __restrict__ part, int R, float* __restrict__ gbn, float* __restrict__ sums,
+                                                          float gscale)
 {
     __shared__ double sh[1024];
     int c = threadIdx.x & 255, q = threadIdx.x >> 8;
@@ -839,8 +852,8 @@ __global__ __launch_bounds__(1024) void t_bn_bwd_finalize(const double* __restri
         s = reduce_q32(s, sh);
         sx = reduce_q32(sx, sh);
         if (q == 0) {
-            gbn[c] = (float)sx;
-            gbn[NF + c] = (float)s;
+            gbn[c] = (float)sx * gscale;
+            gbn[NF + c] = (float)s * gscale;
             sums[c] = (float)s;
             sums[NF + c] = (float)sx;
         }
@@ -853,7 +866,7 @@ __global__ __launch_bounds__(1024) void t_bn_bwd_finalize(const double* __restri
             }
             s = block_sum_1024(s, sh);
             sx = block_sum_1024(sx, sh);
-            if (threadIdx.x == 0) { gbn[g] = (float)sx; gbn[NG + g] = (float)s; sums[g] = (float)s; sums[NF + g] = (float)sx; }
+            if (threadIdx.x == 0) { gbn[g] = (float)sx * gscale; gbn[NG + g] = (float)s * gscale; sums[g] = (float)s; sums[NF + g] = (float)sx; }
         }
     }
 }
@@ -908,8 +921,9 @@ __global__ __launch_bounds__(256) void t_head_conv(const float* __restrict__ H, 
     if (lane == 0) reinterpret_cast<float4*>(pv0)[r] = make_float4(s0, s1, s2, 0.0f);
 }
 
-// batch statistics of the 3 head channels (bn_pi x2, bn_v) + moving averages; single block of 1024 threads
-__global__ __launch_bounds__(1024) void t_head_bn_stats(const float* __restrict__ pv0, int M, float* __restrict__ hp, float* __restrict__ hstat /* mean[3] istd[3] */)
+// batch statistics of the 3 head channels (bn_pi x2, bn_v) + moving averages; single block of 1024 threads.
+// Two stages so that a data-parallel step can all-reduce the six sums in between: hsum = {s[3], ss[3]} (doubles).
+__global__ __launch_bounds__(1024) void t_head_bn_sums(const float* __restrict__ pv0, int M, double* __restrict__ hsum)
 {
     __shared__ double sh[1024];
     for (int ch = 0; ch < 3; ch++) {
@@ -917,16 +931,20 @@ __global__ __launch_bounds__(1024) void t_head_bn_stats(const float* __restrict_
         for (int r = threadIdx.x; r < M; r += 1024) { const double v = pv0[(size_t)r * 4 + ch]; s += v; ss += v * v; }
         s = block_sum_1024(s, sh);
         ss = block_sum_1024(ss, sh);
-        if (threadIdx.x == 0) {
-            const double n = M, mu = s / n, var = fmax(ss / n - mu * mu, 0.0);
-            hstat[ch] = (float)mu;
-            hstat[3 + ch] = (float)(1.0 / sqrt(var + (double)BN_EPS));
-            float* bn = ch < 2 ? hp + H_PI_BN : hp + H_V_BN;
-            const int C = ch < 2 ? 2 : 1, k = ch < 2 ? ch : 0;
-            bn[2 * C + k] = bn[2 * C + k] * BN_KEEP + (float)mu * (1.0f - BN_KEEP);
-            bn[3 * C + k] = bn[3 * C + k] * BN_KEEP + (float)(var * n / (n - 1.0)) * (1.0f - BN_KEEP);
-        }
+        if (threadIdx.x == 0) { hsum[ch] = s; hsum[3 + ch] = ss; }
     }
+}
+__global__ void t_head_bn_stats(const double* __restrict__ hsum, double n, float* __restrict__ hp, float* __restrict__ hstat /* mean[3] istd[3] */)
+{
+    const int ch = threadIdx.x;
+    if (ch >= 3 || blockIdx.x != 0) return;
+    const double mu = hsum[ch] / n, var = fmax(hsum[3 + ch] / n - mu * mu, 0.0);
+    hstat[ch] = (float)mu;
+    hstat[3 + ch] = (float)(1.0 / sqrt(var + (double)BN_EPS));
+    float* bn = ch < 2 ? hp + H_PI_BN : hp + H_V_BN;
+    const int C = ch < 2 ? 2 : 1, k = ch < 2 ? ch : 0;
+    bn[2 * C + k] = bn[2 * C + k] * BN_KEEP + (float)mu * (1.0f - BN_KEEP);
+    bn[3 * C + k] = bn[3 * C + k] * BN_KEEP + (float)(var * n / (n - 1.0)) * (1.0f - BN_KEEP);
 }
 
 __device__ __forceinline__ float head_bn_relu(const float* hp, const float* hstat, float x, int ch)
@@ -987,14 +1005,17 @@ __global__ __launch_bounds__(256) void t_head_fwd(const float* __restrict__ pv0,
 
 // batch means of the two losses (softmax_cross_entropy / mean_squared_error reduce over the batch) -> loss[0..1];
 // acc[0..1] += them (the epoch sums of alphazero_nn.cpp:393-394, float like the reference)
-__global__ void t_loss(const float* __restrict__ lossb, int BS, float* __restrict__ loss, float* __restrict__ acc)
+// (a data-parallel step sums its own boards, divides by the GLOBAL batch, all-reduces loss[0..1], then accumulates)
+__global__ void t_loss(const float* __restrict__ lossb, int BS, int BS_global, float* __restrict__ loss)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float lp = 0.0f, lv = 0.0f;
     for (int b = 0; b < BS; b++) { lp += lossb[b * 2]; lv += lossb[b * 2 + 1]; }
-    lp /= (float)BS; lv /= (float)BS;
-    loss[0] = lp; loss[1] = lv;
-    acc[0] += lp; acc[1] += lv;
+    loss[0] = lp / (float)BS_global; loss[1] = lv / (float)BS_global;
+}
+__global__ void t_loss_acc(const float* __restrict__ loss, float* __restrict__ acc)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { acc[0] += loss[0]; acc[1] += loss[1]; }
 }
 
 // backward of the dense parts; writes dz of the three head BN outputs (dpv [M][4]) and the per-board parameter partials
@@ -1060,9 +1081,10 @@ __global__ void t_head_reduce(const float* __restrict__ hpart, int BS, float* __
     ghead[o] = s;
 }
 
-// BN backward of the 3 head channels in one block: dpv (dz) -> gradients of gamma/beta and dpv := d(conv output)
-__global__ __launch_bounds__(1024) void t_head_bn_bwd(const float* __restrict__ pv0, const float* __restrict__ hp, const float* __restrict__ hstat,
-                                                      int M, float* __restrict__ dpv, float* __restrict__ ghead)
+// BN backward of the 3 head channels: dpv (dz) -> gradients of gamma/beta and dpv := d(conv output).  Two stages (sums,
+// apply) so that a data-parallel step can all-reduce hsum = {s[3], sx[3]} in between; n = rows of the GLOBAL batch.
+__global__ __launch_bounds__(1024) void t_head_bn_bwd_sums(const float* __restrict__ pv0, const float* __restrict__ hstat, int M,
+                                                           const float* __restrict__ dpv, double* __restrict__ hsum)
 {
     __shared__ double sh[1024];
     for (int ch = 0; ch < 3; ch++) {
@@ -1075,15 +1097,24 @@ __global__ __launch_bounds__(1024) void t_head_bn_bwd(const float* __restrict__ 
         }
         s = block_sum_1024(s, sh);
         sx = block_sum_1024(sx, sh);
+        if (threadIdx.x == 0) { hsum[ch] = s; hsum[3 + ch] = sx; }
+    }
+}
+__global__ __launch_bounds__(1024) void t_head_bn_bwd(const float* __restrict__ pv0, const float* __restrict__ hp, const float* __restrict__ hstat,
+                                                      int M, const double* __restrict__ hsum, float n, float gscale, float* __restrict__ dpv,
+                                                      float* __restrict__ ghead)
+{
+    for (int ch = 0; ch < 3; ch++) {
+        const float mu = hstat[ch], is = hstat[3 + ch];
+        const double s = hsum[ch], sx = hsum[3 + ch];
         const int C = ch < 2 ? 2 : 1, k = ch < 2 ? ch : 0, base = ch < 2 ? H_PI_BN : H_V_BN;
-        if (threadIdx.x == 0) { ghead[base + k] = (float)sx; ghead[base + C + k] = (float)s; }
-        const float gamma = hp[base + k], fs = (float)s / (float)M, fsx = (float)sx / (float)M;
+        if (threadIdx.x == 0) { ghead[base + k] = (float)sx * gscale; ghead[base + C + k] = (float)s * gscale; }
+        const float gamma = hp[base + k], fs = (float)s / n, fsx = (float)sx / n;
         for (int r = threadIdx.x; r < M; r += 1024) {
             const float dz = dpv[(size_t)r * 4 + ch];
             const float xh = (pv0[(size_t)r * 4 + ch] - mu) * is;
             dpv[(size_t)r * 4 + ch] = gamma * is * (dz - fs - xh * fsx);
         }
-        __syncthreads();
     }
 }
 
@@ -1129,7 +1160,7 @@ __global__ void t_tick_lr(int* __restrict__ cur, float* __restrict__ lr)
     const double t = (double)(++cur[1]);
     *lr = (float)((double)LR * sqrt(1.0 - pow((double)ADAM_B2, t)) / (1.0 - pow((double)ADAM_B1, t)));
 }
-__global__ void t_tick_batch(int* __restrict__ cur, int BS)
+__global__ void t_tick_batch(int* __restrict__ cur, int BS /* the GLOBAL minibatch */)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) cur[0] += BS;
 }
@@ -1174,7 +1205,13 @@ struct TrainCtx {
     uint16_t *wpf[3] = {nullptr, nullptr, nullptr}, *wpb[2] = {nullptr, nullptr};        // packed kernels: forward / backward-data view
     float *pv0 = nullptr, *dpv = nullptr, *hstat = nullptr, *fpi = nullptr, *fv = nullptr, *h1 = nullptr, *vout = nullptr,
           *prob = nullptr, *lossb = nullptr, *hpart = nullptr, *cpart = nullptr, *loss = nullptr;
-    int* cur = nullptr;    // device: {minibatch offset in perm, Adam step count}
+    int* cur = nullptr;    // device: {minibatch offset in perm, Adam step count, this rank's offset inside the minibatch}
+    // data-parallel step (azr_nn_train_dp): this rank's shard of every minibatch; sums that span the batch are all-reduced
+    int world = 1, rank = 0;
+    azr_allreduce_fn ar = nullptr;
+    void* ar_ctx = nullptr;
+    double* red = nullptr;     // [2 * NG][256] reduced BN partials
+    double* hsum = nullptr;    // [6] head BN sums
     float* lr = nullptr;   // device: this step's bias-corrected learning rate
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
@@ -1260,9 +1297,10 @@ int ctx_ensure(azr_engine* h, int BS)
     TRY(dalloc(h, c, &c->vout, (size_t)BS)); TRY(dalloc(h, c, &c->prob, (size_t)BS * 43)); TRY(dalloc(h, c, &c->lossb, (size_t)BS * 2));
     TRY(dalloc(h, c, &c->hpart, (size_t)BS * HP_FLOATS)); TRY(dalloc(h, c, &c->cpart, (size_t)c->R * 3 * NF));
     TRY(dalloc(h, c, &c->loss, (size_t)4));
-    TRY(dalloc(h, c, &c->cur, (size_t)2)); TRY(dalloc(h, c, &c->lr, (size_t)1));
+    TRY(dalloc(h, c, &c->cur, (size_t)4)); TRY(dalloc(h, c, &c->lr, (size_t)1));
+    TRY(dalloc(h, c, &c->red, (size_t)2 * NG * NF)); TRY(dalloc(h, c, &c->hsum, (size_t)8));
     {
-        const int init[2] = {0, (int)keep_step};
+        const int init[4] = {0, (int)keep_step, 0, 0};
         HIPCHK(h, hipMemcpy(c->cur, init, sizeof init, hipMemcpyHostToDevice));
     }
     TRY(dalloc(h, c, &c->in88, (size_t)BS * 88)); TRY(dalloc(h, c, &c->pit, (size_t)BS * 43)); TRY(dalloc(h, c, &c->zt, (size_t)BS));
@@ -1316,11 +1354,33 @@ void gemm_sb(hipStream_t st, Parts A, int lda, Parts B, int ldb, float* C, int l
 
 inline dim3 grid1(size_t n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
+// one all-reduce (sum, in place) of a device buffer over the ranks of a data-parallel step, through the caller's callback
+// (RCCL over xGMI via torch.distributed on the GPU box).  The engine's stream is drained first: the callback runs on the
+// communicator's own stream and returns when the result is in place.
+int dp_allreduce(azr_engine* h, TrainCtx* c, void* dev, size_t count, int dtype)
+{
+    if (c->world <= 1) return AZR_OK;
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int rc = c->ar(c->ar_ctx, dev, count, dtype);
+    if (rc) { h->err = "azr_nn_train_dp: the all-reduce callback failed with code " + std::to_string(rc); return AZR_E_STATE; }
+    return AZR_OK;
+}
+
 // one optimiser step on the minibatch already gathered into c->in88 / pit / zt
 int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
 {
     hipStream_t st = h->stream;
     const int M = c->M, B = c->blocks, R = c->R, BS = c->BS;
+    // data-parallel: BS / M are this rank's shard, BSg / Mg the whole minibatch every statistic and mean refers to
+    const int W = c->world, BSg = BS * W, Mg = M * W;
+    const bool dp = W > 1;
+    const float gscale = 1.0f / (float)W;
+    // sums over the batch: [local partials -> one slab] -> all-reduce over the ranks -> the finalize kernel reads the slab
+    auto reduce_parts = [&](int K) -> int {
+        hipLaunchKernelGGL(t_parts_sum, dim3(K), dim3(256), 0, st, c->part, R, K, c->red);
+        return dp_allreduce(h, c, c->red, (size_t)K * NF, 1);
+    };
     float* w = h->net.d_flat;
     float* g = c->g;
     const size_t act = (size_t)M * NF, wn_ = (size_t)KC * NF;
@@ -1347,7 +1407,9 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     hipLaunchKernelGGL((t_im2col<SIN>), grid1((size_t)M * 9, 4), dim3(256), 0, st, c->X0, c->col0, M);
     gemm<false, false, 64>(st, c->col0, KS, c->wpad, NF, Yl(0), NF, M, NF, KS);
     hipLaunchKernelGGL((t_bn_stats<true>), dim3(R), dim3(1024), 0, st, Yl(0), M, c->part);
-    hipLaunchKernelGGL((t_bn_finalize<true>), dim3(1), dim3(1024), 0, st, c->part, R, (double)BS * 6 * NF, c->mean, c->istd, w + OFF_STEM_BN);
+    if (dp) TRY(reduce_parts(2 * NG));
+    hipLaunchKernelGGL((t_bn_finalize<true>), dim3(1), dim3(1024), 0, st, dp ? c->red : c->part, dp ? 1 : R, (double)BSg * 6 * NF, c->mean, c->istd,
+                       w + OFF_STEM_BN);
     uint16_t* const nil16 = nullptr;
     // (each layer's normalise kernel also writes the three bf16 parts of its output: the next conv's A operand)
     hipLaunchKernelGGL((t_bn_apply<true>), dim3(g4), dim3(256), 0, st, Yl(0), c->mean, c->istd, w + OFF_STEM_BN, (const float*)nullptr, Al(0), M,
@@ -1359,23 +1421,31 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
             hipLaunchKernelGGL((t_conv_sb<1, 3, 1>), dim3(2, (M + 63) / 64), dim3(256), 0, st, Parts{{c->ap[0], c->ap[1], c->ap[2]}}, Wpf(l), Yl(l), M);
         } else gemm<false, false, 64, 1, 0>(st, Al(l - 1), KC, Wl(l), NF, Yl(l), NF, M, NF, KC);
         hipLaunchKernelGGL((t_bn_stats<false>), dim3(R), dim3(1024), 0, st, Yl(l), M, c->part);
-        hipLaunchKernelGGL((t_bn_finalize<false>), dim3(8), dim3(1024), 0, st, c->part, R, (double)M, c->mean + l * NF, c->istd + l * NF, bn);
+        if (dp) TRY(reduce_parts(2));
+        hipLaunchKernelGGL((t_bn_finalize<false>), dim3(8), dim3(1024), 0, st, dp ? c->red : c->part, dp ? 1 : R, (double)Mg, c->mean + l * NF,
+                           c->istd + l * NF, bn);
         hipLaunchKernelGGL((t_bn_apply<false>), dim3(g4), dim3(256), 0, st, Yl(l), c->mean + l * NF, c->istd + l * NF, bn, S, Al(l), M,
                            (sb && l + 1 < c->L) ? c->ap[0] : nil16, c->ap[1], c->ap[2]);
     }
     const float* H = Al(c->L - 1);
     hipLaunchKernelGGL(t_head_conv, grid1((size_t)M, 4), dim3(256), 0, st, H, hp, c->pv0, M);
-    hipLaunchKernelGGL(t_head_bn_stats, dim3(1), dim3(1024), 0, st, c->pv0, M, hp, c->hstat);
+    hipLaunchKernelGGL(t_head_bn_sums, dim3(1), dim3(1024), 0, st, c->pv0, M, c->hsum);
+    if (dp) TRY(dp_allreduce(h, c, c->hsum, 6, 1));
+    hipLaunchKernelGGL(t_head_bn_stats, dim3(1), dim3(64), 0, st, (const double*)c->hsum, (double)Mg, hp, c->hstat);
     hipLaunchKernelGGL(t_head_fwd, dim3(BS), dim3(256), 0, st, c->pv0, hp, c->hstat, c->pit, c->zt, c->fpi, c->fv, c->h1, c->vout, c->prob, c->lossb);
-    hipLaunchKernelGGL(t_loss, dim3(1), dim3(1), 0, st, c->lossb, BS, c->loss, d_acc);
+    hipLaunchKernelGGL(t_loss, dim3(1), dim3(1), 0, st, c->lossb, BS, BSg, c->loss);
+    if (dp) TRY(dp_allreduce(h, c, c->loss, 2, 0));
+    hipLaunchKernelGGL(t_loss_acc, dim3(1), dim3(1), 0, st, (const float*)c->loss, d_acc);
 
     // ---------------- backward
-    hipLaunchKernelGGL(t_head_bwd, dim3(BS), dim3(256), 0, st, hp, c->pit, c->zt, c->fpi, c->fv, c->h1, c->vout, c->prob, BS, c->dpv, c->hpart);
+    hipLaunchKernelGGL(t_head_bwd, dim3(BS), dim3(256), 0, st, hp, c->pit, c->zt, c->fpi, c->fv, c->h1, c->vout, c->prob, BSg, c->dpv, c->hpart);
     hipLaunchKernelGGL(t_head_reduce, grid1(HP_FLOATS, 256), dim3(256), 0, st, c->hpart, BS, gh);
-    hipLaunchKernelGGL(t_head_bn_bwd, dim3(1), dim3(1024), 0, st, c->pv0, hp, c->hstat, M, c->dpv, gh);
+    hipLaunchKernelGGL(t_head_bn_bwd_sums, dim3(1), dim3(1024), 0, st, c->pv0, c->hstat, M, (const float*)c->dpv, c->hsum);
+    if (dp) TRY(dp_allreduce(h, c, c->hsum, 6, 1));
+    hipLaunchKernelGGL(t_head_bn_bwd, dim3(1), dim3(1024), 0, st, c->pv0, hp, c->hstat, M, (const double*)c->hsum, (float)Mg, gscale, c->dpv, gh);
     hipLaunchKernelGGL(t_head_conv_bwd, dim3(R), dim3(256), 0, st, H, c->dpv, hp, M, c->G, c->cpart);
     hipLaunchKernelGGL(t_head_conv_bwd_finalize, dim3(1), dim3(256), 0, st, c->cpart, R, gh);
-    const float invM = 1.0f / (float)M;
+    const float invM = 1.0f / (float)Mg;
     const size_t wn = wn_;
     for (int l = c->L - 1; l >= 1; l--) {
         // gradient w.r.t. this layer's post-activation output: G for the second conv of a block, DT for the first
@@ -1384,7 +1454,8 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         float* bn = Wl(l) + wn;
         float* gbn = Gl(l) + wn;
         hipLaunchKernelGGL((t_bn_bwd_stats<false>), dim3(R), dim3(1024), 0, st, dOut, Al(l), Yl(l), c->mean + l * NF, c->istd + l * NF, M, c->part);
-        hipLaunchKernelGGL((t_bn_bwd_finalize<false>), dim3(8), dim3(1024), 0, st, c->part, R, gbn, c->sums);
+        if (dp) TRY(reduce_parts(2));
+        hipLaunchKernelGGL((t_bn_bwd_finalize<false>), dim3(8), dim3(1024), 0, st, dp ? c->red : c->part, dp ? 1 : R, gbn, c->sums, gscale);
         hipLaunchKernelGGL((t_bn_bwd_apply<false>), dim3(g4), dim3(256), 0, st, dOut, Al(l), Yl(l), c->mean + l * NF, c->istd + l * NF, bn, c->sums,
                            invM, c->dY, second ? c->DS : (float*)nullptr, M, sb ? c->dyp[0] : nil16, c->dyp[1]);
         // dW = col(input)^T x dY  (implicit im2col, split-K over the M rows)
@@ -1402,17 +1473,21 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     }
     {   // stem: parameters only
         hipLaunchKernelGGL((t_bn_bwd_stats<true>), dim3(R), dim3(1024), 0, st, c->G, Al(0), Yl(0), c->mean, c->istd, M, c->part);
-        hipLaunchKernelGGL((t_bn_bwd_finalize<true>), dim3(1), dim3(1024), 0, st, c->part, R, g + OFF_STEM_BN, c->sums);
+        if (dp) TRY(reduce_parts(2 * NG));
+        hipLaunchKernelGGL((t_bn_bwd_finalize<true>), dim3(1), dim3(1024), 0, st, dp ? c->red : c->part, dp ? 1 : R, g + OFF_STEM_BN, c->sums, gscale);
         hipLaunchKernelGGL((t_bn_bwd_apply<true>), dim3(g4), dim3(256), 0, st, c->G, Al(0), Yl(0), c->mean, c->istd, w + OFF_STEM_BN, c->sums,
-                           1.0f / ((float)BS * 6 * NF), c->dY, (float*)nullptr, M, nil16, nil16);
+                           1.0f / ((float)BSg * 6 * NF), c->dY, (float*)nullptr, M, nil16, nil16);
         gemm<true, false>(st, c->col0, KS, c->dY, NF, c->wpart, NF, KS, NF, M, c->nz, c->kchunk, (size_t)KS * NF);
         hipLaunchKernelGGL(t_sum_slices, grid1((size_t)KS * NF, 256), dim3(256), 0, st, c->wpart, c->nz, (size_t)KS * NF, c->gpad);
         hipLaunchKernelGGL(t_stem_unpad, grid1((size_t)9 * 13 * NF, 256), dim3(256), 0, st, c->gpad, g);
     }
+    // ---------------- data-parallel: the ranks' gradient vectors add up to the gradient of the whole minibatch (one RCCL
+    //                  all-reduce of count floats: 94.7 MB at B = 20); every rank then takes the same Adam step
+    if (dp) TRY(dp_allreduce(h, c, g, c->count, 0));
     // ---------------- Adam
     hipLaunchKernelGGL(t_tick_lr, dim3(1), dim3(1), 0, st, c->cur, c->lr);
     hipLaunchKernelGGL(t_adam, grid1(c->count, 256), dim3(256), 0, st, w, g, c->m, c->v, c->kind, c->count, (const float*)c->lr);
-    hipLaunchKernelGGL(t_tick_batch, dim3(1), dim3(1), 0, st, c->cur, BS);
+    hipLaunchKernelGGL(t_tick_batch, dim3(1), dim3(1), 0, st, c->cur, BSg);
     HIPCHK(h, hipGetLastError());
     return AZR_OK;
 }
@@ -1425,7 +1500,7 @@ int run_step(azr_engine* h, TrainCtx* c)
 {
     static const bool use_graph = getenv("AZR_TRAIN_GRAPH") && atoi(getenv("AZR_TRAIN_GRAPH")) != 0;
     c->step++;
-    if (!use_graph) {
+    if (!use_graph || c->world > 1) {   // (host callbacks of the data-parallel step cannot be captured)
         hipLaunchKernelGGL(t_gather, dim3(c->BS), dim3(64), 0, h->stream, c->rec, c->perm, (const int*)c->cur, c->BS, c->in88, c->pit, c->zt);
         return train_step(h, c, c->loss + 2);
     }
@@ -1497,7 +1572,11 @@ extern "C" int azr_nn_train_batch(azr_engine* h, const void* rec265_host, int n,
     std::vector<int> id(n);
     for (int i = 0; i < n; i++) id[i] = i;
     HIPCHK(h, hipMemcpyAsync(c->perm, id.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(c->cur, 0, sizeof(int), h->stream));
+    {
+        const int cur3[3] = {0, (int)c->step, 0};
+        HIPCHK(h, hipMemcpyAsync(c->cur, cur3, sizeof cur3, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     HIPCHK(h, hipMemsetAsync(c->loss + 2, 0, 2 * sizeof(float), h->stream));
     TRY(run_step(h, c));
     float l[2];
@@ -1508,12 +1587,19 @@ extern "C" int azr_nn_train_batch(azr_engine* h, const void* rec265_host, int n,
     return AZR_OK;
 }
 
-extern "C" int azr_nn_train(azr_engine* h, const void* rec265_host, size_t n, int epochs, int batch_size, uint32_t* shuffle_rng_state,
-                            float* loss_pi_host, float* loss_v_host)
+// AlphaZeroNN::train for rank `rank` of `world` data-parallel ranks (world = 1: the reference's single-GPU training).  Every
+// rank holds ALL n records and the same shuffle stream; of each minibatch of batch_size records rank r takes the slice
+// [r * batch_size / world, (r + 1) * batch_size / world).
+static int train_impl(azr_engine* h, const void* rec265_host, size_t n, int epochs, int batch_size, uint32_t* shuffle_rng_state, int rank,
+                      int world, azr_allreduce_fn ar, void* ar_ctx, float* loss_pi_host, float* loss_v_host)
 {
-    ENTER(h);
     if (!h->weights_set) { h->err = "azr_nn_train: no weights"; return AZR_E_STATE; }
     if (!rec265_host || epochs < 0 || batch_size < 2) { h->err = "azr_nn_train: bad arguments"; return AZR_E_INVALID_ARGUMENT; }
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && !ar) || batch_size % world != 0 || batch_size / world < 2) {
+        h->err = "azr_nn_train_dp: need 0 <= rank < world, an all-reduce callback, and batch_size a multiple of world with >= 2 records per rank";
+        return AZR_E_INVALID_ARGUMENT;
+    }
+    const int local_bs = batch_size / world;
     const size_t batches = n / (size_t)batch_size;  // the remainder of an epoch is dropped (alphazero_nn.cpp:374)
     std::minstd_rand0 eng;                          // RNG.getEngine() (src/rng.h:5-50): the caller's stream continues here
     if (shuffle_rng_state) {
@@ -1525,18 +1611,23 @@ extern "C" int azr_nn_train(azr_engine* h, const void* rec265_host, size_t n, in
     for (size_t i = 0; i < n; i++) order[i] = (int)i;
     TrainCtx* c = nullptr;
     if (batches > 0 && epochs > 0) {
-        TRY(ctx_ensure(h, batch_size));
+        TRY(ctx_ensure(h, local_bs));
         c = ctx_of(h);
+        c->world = world; c->rank = rank; c->ar = ar; c->ar_ctx = ar_ctx;
         TRY(upload_records(h, c, rec265_host, n));
     }
-    for (int e = 0; e < epochs; e++) {
+    int rc = AZR_OK;
+    for (int e = 0; e < epochs && rc == AZR_OK; e++) {
         std::shuffle(order.begin(), order.end(), eng);  // alphazero_nn.cpp:372 (same libstdc++ algorithm, same engine)
         float l[2] = {NAN, NAN};
         if (batches > 0) {
+            const int cur3[3] = {0, (int)c->step, rank * local_bs};   // minibatch offset, Adam step count, this rank's slice
             HIPCHK(h, hipMemcpyAsync(c->perm, order.data(), n * sizeof(int), hipMemcpyHostToDevice, h->stream));
             HIPCHK(h, hipMemsetAsync(c->loss + 2, 0, 2 * sizeof(float), h->stream));
-            HIPCHK(h, hipMemsetAsync(c->cur, 0, sizeof(int), h->stream));
-            for (size_t b = 0; b < batches; b++) TRY(run_step(h, c));
+            HIPCHK(h, hipMemcpyAsync(c->cur, cur3, sizeof cur3, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            for (size_t b = 0; b < batches && rc == AZR_OK; b++) rc = run_step(h, c);
+            if (rc) break;
             HIPCHK(h, hipMemcpyAsync(l, c->loss + 2, sizeof l, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
             l[0] /= (float)batches;
@@ -1545,6 +1636,8 @@ extern "C" int azr_nn_train(azr_engine* h, const void* rec265_host, size_t n, in
         if (loss_pi_host) loss_pi_host[e] = l[0];
         if (loss_v_host) loss_v_host[e] = l[1];
     }
+    if (c) { c->world = 1; c->rank = 0; c->ar = nullptr; c->ar_ctx = nullptr; }
+    if (rc) return rc;
     if (shuffle_rng_state) {
         // minstd_rand0 has no state accessor; operator<< prints the state as decimal text
         std::ostringstream os;
@@ -1553,6 +1646,20 @@ extern "C" int azr_nn_train(azr_engine* h, const void* rec265_host, size_t n, in
     }
     if (batches > 0 && epochs > 0) TRY(finish(h));
     return AZR_OK;
+}
+
+extern "C" int azr_nn_train(azr_engine* h, const void* rec265_host, size_t n, int epochs, int batch_size, uint32_t* shuffle_rng_state,
+                            float* loss_pi_host, float* loss_v_host)
+{
+    ENTER(h);
+    return train_impl(h, rec265_host, n, epochs, batch_size, shuffle_rng_state, 0, 1, nullptr, nullptr, loss_pi_host, loss_v_host);
+}
+
+extern "C" int azr_nn_train_dp(azr_engine* h, const void* rec265_host, size_t n, int epochs, int batch_size, uint32_t* shuffle_rng_state,
+                               int rank, int world, azr_allreduce_fn allreduce, void* ctx, float* loss_pi_host, float* loss_v_host)
+{
+    ENTER(h);
+    return train_impl(h, rec265_host, n, epochs, batch_size, shuffle_rng_state, rank, world, allreduce, ctx, loss_pi_host, loss_v_host);
 }
 
 extern "C" int azr_nn_train_grads(azr_engine* h, float* flat_host, size_t count)

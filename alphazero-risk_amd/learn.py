@@ -189,14 +189,25 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
         # ---- trainGroup->train (alphazero_gpu_cluster.cpp:221-231)
         t0 = time.time()
         hist = []
-        if rank == 0:   # AlphaZeroNNGroup::train: the first GPU trains (alphazero_gpu_cluster.cpp:221-231)
-            hist, shuffle_state = new.train(records, a.e, batch_size=a.bs, rng_state=shuffle_state)
+        dp = dist is not None and bool(getattr(a, "dp", 1)) and a.bs % world == 0 and a.bs // world >= 2
+        if dp:
+            # data-parallel optimiser step: every rank takes 1/world of each minibatch (same shuffle stream everywhere);
+            # batch statistics, losses and the gradient vector are all-reduced (RCCL over xGMI), every rank takes the
+            # same Adam step — no weight broadcast
+            hist, shuffle_state = new.train_dp(records, a.e, shard_mod.make_allreduce(dist, cdev != "cpu"), rank, world,
+                                               batch_size=a.bs, rng_state=shuffle_state)
             hist = [h for h in hist if not np.isnan(h[0])]
-            nn_log.write(nn_training_line(hist)); nn_log.flush()
-        if dist is not None:   # ... and the others receive its weights
-            w = shard_mod.broadcast_flat(new.get_weights(), dist, src=0, device=cdev)
-            if rank != 0:
-                new.set_weights(w)
+            if rank == 0:
+                nn_log.write(nn_training_line(hist)); nn_log.flush()
+        else:
+            if rank == 0:   # AlphaZeroNNGroup::train: the first GPU trains (alphazero_gpu_cluster.cpp:221-231)
+                hist, shuffle_state = new.train(records, a.e, batch_size=a.bs, rng_state=shuffle_state)
+                hist = [h for h in hist if not np.isnan(h[0])]
+                nn_log.write(nn_training_line(hist)); nn_log.flush()
+            if dist is not None:   # ... and the others receive its weights
+                w = shard_mod.broadcast_flat(new.get_weights(), dist, src=0, device=cdev)
+                if rank != 0:
+                    new.set_weights(w)
         steps = a.e * (len(records) // a.bs)
         if hist:
             log(f"Loss Policy / Value: {hist[-1][0]:f} / {hist[-1][1]:f}   [{steps} steps, {1e3 * (time.time() - t0) / max(steps, 1):.1f} ms/step]")
@@ -261,6 +272,9 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--include-compare-samples", type=int, default=1)   # INCLUDE_COMPARE_GAMES_TRAIN_SAMPLES
+    ap.add_argument("--dp", type=int, default=1,
+                    help="multi-rank runs: 1 = data-parallel optimiser step over all ranks (default), 0 = rank 0 trains and broadcasts "
+                         "(the reference's AlphaZeroNNGroup::train)")
     a = ap.parse_args()
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1:

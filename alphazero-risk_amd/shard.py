@@ -76,6 +76,35 @@ def broadcast_flat(flat, dist=None, src=0, device="cpu"):
     return t.cpu().numpy()
 
 
+class _DevicePtr:
+    """a raw device allocation seen through the CUDA array interface (torch.as_tensor aliases it, no copy)"""
+
+    def __init__(self, ptr, count, dtype):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f4" if dtype == 0 else "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def make_allreduce(dist, on_device):
+    """the callback azr_nn_train_dp wants: sum a device buffer of the engine over the ranks, in place.
+    on_device (backend "nccl" = RCCL over xGMI): the collective runs on the buffer itself.  Otherwise (gloo rehearsal, ranks
+    sharing a GPU): staged through a host tensor.  Returns when the result is in place."""
+    import torch
+
+    _one_hip_runtime()
+
+    def allreduce(ptr, count, dtype):
+        t = torch.as_tensor(_DevicePtr(ptr, count, dtype), device="cuda")
+        if on_device:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        else:
+            c = t.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            t.copy_(c)
+        torch.cuda.synchronize()
+
+    return allreduce
+
+
 def device_records_to_torch(eng, device):
     """the engine's finished records as a torch uint8 tensor [n, 265] on `device` (the GPU the engine runs on): one
     device-to-device copy on the engine's own stream (azr_samples_copy_device) — the send buffer of the record gather.

@@ -114,6 +114,18 @@ int azr_nn_predict(azr_engine* h, const void* in88_host, int n, float* pi_host, 
  * handle across calls like the TF session's slots; inference weights are refolded / repacked before returning. */
 int azr_nn_train(azr_engine* h, const void* rec265_host, size_t n, int epochs, int batch_size,
                  uint32_t* shuffle_rng_state, float* loss_pi_host, float* loss_v_host);
+/* Data-parallel AlphaZeroNN::train: the same epochs / shuffles / minibatches, every minibatch split over `world` ranks
+ * (one process per GPU; the reference trains on GPU 0 only and hands the weights over through checkpoints/temp.bin,
+ * alphazero_gpu_cluster.cpp:221-231).  Every rank passes ALL n records and the same *shuffle_rng_state and takes slice
+ * `rank` of each minibatch (batch_size % world == 0).  Whatever spans the minibatch — batch-norm statistics in the
+ * forward pass, their two sums in the backward pass, the losses, and at the end of the step the whole gradient vector
+ * (azr_nn_param_count floats) — is summed over the ranks through `allreduce`: in place on DEVICE memory of this GPU,
+ * dtype 0 = float32, 1 = float64, return 0 on success; the engine's stream is idle while it runs.  All ranks then take the
+ * same Adam step, so their weights stay equal without a broadcast, and equal the single-GPU step's up to summation
+ * order.  world = 1 is azr_nn_train. */
+typedef int (*azr_allreduce_fn)(void* ctx, void* device_ptr, size_t count, int dtype);
+int azr_nn_train_dp(azr_engine* h, const void* rec265_host, size_t n, int epochs, int batch_size, uint32_t* shuffle_rng_state,
+                    int rank, int world, azr_allreduce_fn allreduce, void* ctx, float* loss_pi_host, float* loss_v_host);
 /* one `session->Run(..., {optimize})` (alphazero_nn.cpp:389-391) on exactly n records in the given order */
 int azr_nn_train_batch(azr_engine* h, const void* rec265_host, int n, float* loss_pi, float* loss_v);
 /* diagnostics: gradient vector of the last step in AZRW layout (moving-statistics slots unused) */
@@ -212,6 +224,10 @@ int azr_arena_log(azr_engine* h, int32_t* games_per_slot_host, int8_t* status_ho
  * azr_selfplay_run, measured with HIP events on the engine's stream */
 int azr_profile_last_run(azr_engine* h, float* net_ms_avg, float* tree_ms_avg, int* launches);
 int azr_device_synchronize(azr_engine* h);
+/* diagnostics of the tower kernels (tools/tower_clock.py, tools/tower_trace.py): sustained in-kernel shader clock and
+ * workgroup-0 time after `warm` back-to-back launches on n leaf slots; per-workgroup time stamps of one launch */
+int azr_debug_tower_clock(azr_engine* h, int n, int warm, double* ghz_out, double* tower_ms_out);
+int azr_debug_tower_trace(azr_engine* h, int n, int warm, unsigned long long* out5, int cap_wgs, int* wgs_out);
 
 #ifdef __cplusplus
 }
