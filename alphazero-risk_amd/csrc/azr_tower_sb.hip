@@ -12,9 +12,10 @@
 //     registers instead of in a second image: 88 registers per lane;
 //   * 4 waves (one per SIMD, up to 512 registers each) split the 256 output channels, 64 (four 16-wide tiles) each, so an
 //     activation fragment read from LDS feeds 4 MFMAs: LDS fragment traffic per MFMA is half that of the 8-wave tiles;
-//   * per k-step a wave issues, tile by tile, [4 MFMAs | 1 ds_read_b128 of that tile's NEXT k-step fragment], then the 4
-//     buffer loads that refill the weight-ring slot just consumed (ring = 4 k-steps ahead, never drained; the packed
-//     stream of all layers is contiguous, exactly as for k_tower_bf16 — both kernels read the same packed weights);
+//   * per k-step a wave issues, tile by tile, [4 MFMAs | 1 ds_read_b128 of that tile's NEXT k-step fragment]; the 4 buffer
+//     loads that refill the weight-ring slot freed by the previous k-step are dealt out over the k-step, one per MFMA gap
+//     (ring of 4 slots, 3 k-steps ahead, never drained; the packed stream of all layers is contiguous, exactly as for
+//     k_tower_bf16 — both kernels read the same packed weights);
 //   * the layer loop is rolled (conv1 and conv2 of a block share the code; only the epilogue looks at the parity) and a
 //     layer's 72 k-steps are fully unrolled with compile-time skip masks: ~40 KB of straight-line code, inside the
 //     64 KB instruction cache.
@@ -83,6 +84,13 @@ __host__ __device__ constexpr uint32_t skip_mask4(int tap)
     return (ty == 0 ? 0x11u : ty == 2 ? 0x2u : 0u) | (tx == 0 ? 0x4u : tx == 2 ? 0x8u : 0u);
 }
 
+// s_waitcnt lgkmcnt(N) alone (vmcnt / expcnt untouched)
+template <int N>
+__device__ __forceinline__ void wait_lgkm()
+{
+    if constexpr (N >= 0 && N <= 14) __builtin_amdgcn_s_waitcnt(0xC07F | (N << 8));
+}
+
 __device__ __forceinline__ s16x8 lds16(const uint8_t* p) { return *reinterpret_cast<const s16x8*>(p); }
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -110,6 +118,63 @@ __device__ __forceinline__ uint2 bn_relu_pack(const f32x4& acc, const float4& s,
     const s16x2 a = __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(lo, bf16x2)), z);
     const s16x2 b = __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(hi, bf16x2)), z);
     return uint2{__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b)};
+}
+
+// One tap (8 k-steps of 32 input channels) of a 3x3 conv layer for the 11 row tiles x 4 column tiles of a wave.  Everything
+// that depends on the tap — which tiles run (skip masks), ring slots, wait counts — is a compile-time constant.
+//
+// Issue order.  A lone wave issues one instruction per ~4 cycles and an MFMA occupies the issue port for 8 of its 16 cycles:
+// whatever else sits in one MFMA gap beyond ~8 cycles delays the matrix pipe.  So the non-MFMA work of a k-step is dealt out
+// one piece per gap instead of in bursts:
+//   k-step start:  one counted vmcnt wait for all four weight fragments of this k-step (the loads of the two k-steps in
+//                  flight behind them stay outstanding)
+//   per tile:      M0 | [one refill load] | M1 | [wait for the NEXT tile's fragment] | M2 | M3 | re-read of this tile's
+//                  fragment for the next k-step
+// The compiler's own waitcnt insertion still runs afterwards and stays the safety net: an explicit wait only moves a wait
+// to an earlier, cheaper place.
+template <int TAP>
+__device__ __forceinline__ void conv_tap4(const uint8_t* bufX, const uint8_t* tr_c, uint32_t g16, const __amdgpu_buffer_rsrc_t wsrc,
+                                          uint32_t loff, uint32_t& wk, u32x4 (&bq)[RING][NT], f32x4 (&acc)[MT][NT], s16x8 (&a)[MT],
+                                          uint32_t (&ap)[MT])
+{
+    constexpr uint32_t sk = skip_mask4(TAP), skn = skip_mask4(TAP + 1);
+    constexpr int active = MT - __builtin_popcount(sk & ((1u << MT) - 1u));   // tiles that run this tap
+    uint32_t np[MT];
+#pragma unroll
+    for (int ks = 0; ks < KS_PER_TAP; ks++) {
+        const int gk = TAP * KS_PER_TAP + ks;                       // k-step inside the layer (72 = 0 mod RING)
+        const int cur = gk % RING, ref = (gk + RING - 1) % RING;    // ring slot in use / slot freed by the previous k-step
+        if (ks == KS_PER_TAP - 3) {   // the next tap's source rows, a little before they are needed
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) np[mt] = (uint32_t)tr_c[(TAP + 1) * ZR + mt * 16] * ROWB + g16;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NT));              // vmcnt(8); lgkmcnt / expcnt untouched
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            if (!((sk >> mt) & 1u)) {
+                const int j = __builtin_popcount(~sk & ((1u << mt) - 1u));   // index among the active tiles
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[cur][0]), __builtin_bit_cast(bf16x8, a[mt]), acc[mt][0], 0, 0, 0);
+                // refill of the slot the previous k-step freed, RING - 1 k-steps ahead: one of its 4 loads after the first
+                // MFMA of 4 tiles spread over the k-step (also across layer boundaries)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+                    if (j == ((nt + 1) * active) / NT - 1)
+                        bq[ref][nt] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, loff + nt * 1024, (int)(wk + (RING - 1) * KBYTES), 0);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[cur][1]), __builtin_bit_cast(bf16x8, a[mt]), acc[mt][1], 0, 0, 0);
+                wait_lgkm<active - 2>();                            // the next tile's fragment was requested `active - 1` reads ago
+                __builtin_amdgcn_sched_barrier(0);
+                acc[mt][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[cur][2]), __builtin_bit_cast(bf16x8, a[mt]), acc[mt][2], 0, 0, 0);
+                acc[mt][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[cur][3]), __builtin_bit_cast(bf16x8, a[mt]), acc[mt][3], 0, 0, 0);
+                if (ks < KS_PER_TAP - 1) a[mt] = lds16(bufX + ap[mt] + (ks + 1) * 64);
+            }
+            if (ks == KS_PER_TAP - 1) { if (!((skn >> mt) & 1u)) a[mt] = lds16(bufX + np[mt]); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wk += (uint32_t)KBYTES;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) ap[mt] = np[mt];
 }
 
 __global__ __launch_bounds__(THREADS, 1) void k_tower_sb4(const uint8_t* __restrict__ in88, int in_stride, int n,
@@ -143,7 +208,8 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb4(const uint8_t* __restr
     uint32_t wk = 0;                                                     // byte offset of the current k-step (wave-uniform)
     u32x4 bq[RING][NT];
 #pragma unroll
-    for (int ks = 0; ks < RING; ks++)
+    for (int ks = 0; ks < RING - 1; ks++)   // (slot RING - 1 is filled during k-step 0, and so on: the refill of a slot is
+                                            //  issued during the k-step after the one that used it)
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) bq[ks][nt] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, loff + nt * 1024, ks * (int)KBYTES, 0);
 
@@ -256,38 +322,15 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb4(const uint8_t* __restr
                 sh[nt] = *reinterpret_cast<const float4*>(fs + NF + nt * 16);
             }
         }
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) {   // fully unrolled: skip masks are compile-time, no branch in the layer's main loop
-            const uint32_t sk = skip_mask4(tap), skn = skip_mask4(tap + 1);
-            uint32_t np[MT];
-#pragma unroll
-            for (int ks = 0; ks < KS_PER_TAP; ks++) {
-                if (ks == KS_PER_TAP - 3) {   // the next tap's source rows, a little before they are needed
-#pragma unroll
-                    for (int mt = 0; mt < MT; mt++) np[mt] = (uint32_t)tr_c[(tap + 1) * ZR + mt * 16] * ROWB + g16;
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++) {
-                    if (!((sk >> mt) & 1u)) {
-#pragma unroll
-                        for (int nt = 0; nt < NT; nt++)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[ks % RING][nt]),
-                                                                                  __builtin_bit_cast(bf16x8, a[mt]), acc[mt][nt], 0, 0, 0);
-                        if (ks < KS_PER_TAP - 1) a[mt] = lds16(bufX + ap[mt] + (ks + 1) * 64);
-                    }
-                    if (ks == KS_PER_TAP - 1) { if (!((skn >> mt) & 1u)) a[mt] = lds16(bufX + np[mt]); }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // the ring slot just consumed is refilled RING k-steps ahead (also across layer boundaries)
-#pragma unroll
-                for (int nt = 0; nt < NT; nt++)
-                    bq[ks % RING][nt] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, loff + nt * 1024, (int)(wk + RING * KBYTES), 0);
-                wk += (uint32_t)KBYTES;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) ap[mt] = np[mt];
-        }
+        conv_tap4<0>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap4<1>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap4<2>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap4<3>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap4<4>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap4<5>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap4<6>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap4<7>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap4<8>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
         __syncthreads();        // every wave has read the image for the last time
         if (L & 1) {    // second conv of a block: + shortcut (the block's input, kept packed in registers), and this
                         // output is the next block's input
