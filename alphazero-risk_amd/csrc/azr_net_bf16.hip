@@ -664,14 +664,14 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
 
 // Diagnostics (not part of the product path).  azr_debug_tower_clock: sustained shader clock of the tower kernel under load
 // = d(s_memtime) / d(s_memrealtime) x 100 MHz around workgroup 0's whole tower, after `warm` back-to-back launches on the
-// leaf buffers.  azr_debug_tower_trace: per workgroup of that launch (k_tower_sb4 only) 5 words: 100 MHz real-time at kernel
-// start, tower start, tower end, kernel end, and the XCC id.
+// leaf buffers.  azr_debug_tower_trace: per workgroup of that launch (k_tower_sb4 only) 8 words: 100 MHz real-time at kernel
+// start, tower start, tower end, kernel end, the XCC id, and the shader-clock counter at tower start / end.
 static int tower_diag_run(azr_engine* h, int n, int warm, std::vector<unsigned long long>& v)
 {
     if (!h || !h->net.bf16ctx || !h->weights_set) return AZR_E_STATE;
     Bf16Net* x = bn(h);
     unsigned long long* d = nullptr;
-    const size_t words = 8 + 5 * (size_t)(n > 0 ? n : 1);
+    const size_t words = 8 + 8 * (size_t)(n > 0 ? n : 1);
     HIPCHK(h, hipMalloc((void**)&d, words * sizeof(unsigned long long)));
     HIPCHK(h, hipMemsetAsync(d, 0, words * sizeof(unsigned long long), h->stream));
     for (int i = 0; i < warm; i++) net_bf16_forward(h, h->d.leaf_in, LEAF_STRIDE, n, h->d.net_pi, h->d.net_v, nullptr, h->stream);
@@ -696,15 +696,15 @@ extern "C" int azr_debug_tower_clock(azr_engine* h, int n, int warm, double* ghz
     return AZR_OK;
 }
 
-extern "C" int azr_debug_tower_trace(azr_engine* h, int n, int warm, unsigned long long* out5, int cap_wgs, int* wgs_out)
+extern "C" int azr_debug_tower_trace(azr_engine* h, int n, int warm, unsigned long long* out8, int cap_wgs, int* wgs_out)
 {
     std::vector<unsigned long long> v;
     int rc = tower_diag_run(h, n, warm, v);
     if (rc) return rc;
     int wgs = 0;
     for (int i = 0; i < n && i < cap_wgs; i++) {
-        if (v[8 + 5 * (size_t)i] == 0) break;
-        for (int k = 0; k < 5; k++) out5[5 * (size_t)i + k] = v[8 + 5 * (size_t)i + k];
+        if (v[8 + 8 * (size_t)i] == 0) break;
+        for (int k = 0; k < 8; k++) out8[8 * (size_t)i + k] = v[8 + 8 * (size_t)i + k];
         wgs++;
     }
     if (wgs_out) *wgs_out = wgs;

@@ -194,12 +194,12 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb4(const uint8_t* __restr
     const int c = lane & 15, g = lane >> 4;        // MFMA fragment coordinates: board cell (column) c of a tile, k-group g
     const int board0 = blockIdx.x * NB;
     // diagnostics (azr_debug_tower_clock / azr_debug_tower_trace; `diag` is null in every product launch): workgroup 0's
-    // shader-clock / real-time stamps around the tower, and per workgroup 5 words from diag[8 + 5 * blockIdx]: real-time
+    // shader-clock / real-time stamps around the tower, and per workgroup 8 words from diag[8 + 8 * blockIdx]: real-time
     // at kernel start, tower start, tower end, kernel end, and the XCC the workgroup ran on
     if (diag && blockIdx.x == 0 && tid == 0) { diag[0] = __builtin_amdgcn_s_memtime(); diag[1] = __builtin_amdgcn_s_memrealtime(); }
     if (diag && tid == 0) {
-        diag[8 + 5 * (size_t)blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-        diag[8 + 5 * (size_t)blockIdx.x + 4] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (3 << 11)) & 15u;
+        diag[8 + 8 * (size_t)blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        diag[8 + 8 * (size_t)blockIdx.x + 4] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (3 << 11)) & 15u;
     }
 
     // ---- weight ring: the first RING k-steps of layer 0 fly while the tables and the stem are built
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb4(const uint8_t* __restr
     }
     __syncthreads();
 
-    if (diag && tid == 0) diag[8 + 5 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    if (diag && tid == 0) { diag[8 + 8 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); diag[8 + 8 * (size_t)blockIdx.x + 5] = __builtin_amdgcn_s_memtime(); }
     // ---- residual tower: 2B conv layers, activations resident in the one LDS image
     const uint8_t* tr_c = taprow + c;           // this lane's column of the (tap, row) -> source-row table
     const uint32_t g16 = (uint32_t)g * 16u;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb4(const uint8_t* __restr
     }
 
     if (diag && blockIdx.x == 0 && tid == 0) { diag[2] = __builtin_amdgcn_s_memtime(); diag[3] = __builtin_amdgcn_s_memrealtime(); }
-    if (diag && tid == 0) diag[8 + 5 * (size_t)blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    if (diag && tid == 0) { diag[8 + 8 * (size_t)blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime(); diag[8 + 8 * (size_t)blockIdx.x + 6] = __builtin_amdgcn_s_memtime(); }
     // ---- both heads (build_graph.py:76-90; the arithmetic of k_tower_bf16's fused heads, same order)
     {
         const float* wpi = hp;              // [256][2]
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb4(const uint8_t* __restr
             }
         }
     }
-    if (diag && tid == 0) diag[8 + 5 * (size_t)blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    if (diag && tid == 0) diag[8 + 8 * (size_t)blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
 }
 }  // namespace
 

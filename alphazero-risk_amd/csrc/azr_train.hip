@@ -1255,8 +1255,9 @@ void ctx_free(TrainCtx* c)
 int ctx_ensure(azr_engine* h, int BS)
 {
     TrainCtx* c = ctx_of(h);
-    if (const char* e = getenv("AZR_TRAIN_GEMM")) g_gemm_bf16x3 = strcmp(e, "f32") != 0;
     if (c && c->BS == BS) return AZR_OK;
+    // tuning switch, read when a training context is (re)built — never in the step path
+    g_gemm_bf16x3 = !(getenv("AZR_TRAIN_GEMM") && strcmp(getenv("AZR_TRAIN_GEMM"), "f32") == 0);
     // a different batch size rebuilds the activation slabs but keeps the optimiser state
     std::vector<float> keep_m, keep_v;
     long keep_step = 0;

@@ -227,7 +227,7 @@ int azr_device_synchronize(azr_engine* h);
 /* diagnostics of the tower kernels (tools/tower_clock.py, tools/tower_trace.py): sustained in-kernel shader clock and
  * workgroup-0 time after `warm` back-to-back launches on n leaf slots; per-workgroup time stamps of one launch */
 int azr_debug_tower_clock(azr_engine* h, int n, int warm, double* ghz_out, double* tower_ms_out);
-int azr_debug_tower_trace(azr_engine* h, int n, int warm, unsigned long long* out5, int cap_wgs, int* wgs_out);
+int azr_debug_tower_trace(azr_engine* h, int n, int warm, unsigned long long* out8, int cap_wgs, int* wgs_out);
 
 #ifdef __cplusplus
 }

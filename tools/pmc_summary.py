@@ -22,7 +22,7 @@ def main():
                 acc[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
     print("kernel,counter,dispatches,mean,min,max")
     for (k, c), v in sorted(acc.items(), key=lambda kv: (kv[0][1], -sum(kv[1]))):
-        print(f"{k},{c},{len(v)},{sum(v) / len(v):.2f},{min(v):.2f},{max(v):.2f}")
+        print(f"\"{k}\",{c},{len(v)},{sum(v) / len(v):.2f},{min(v):.2f},{max(v):.2f}")
 
 
 if __name__ == "__main__":

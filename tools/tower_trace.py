@@ -17,7 +17,7 @@ for n in [int(x) for x in sys.argv[1:]] or [1024, 4096]:
     e.init_random(1)
     e.selfplay_start(1)
     e.selfplay_run(20)
-    out = np.zeros((n, 5), np.uint64)
+    out = np.zeros((n, 8), np.uint64)
     wgs = C.c_int(0)
     rc = L.azr_debug_tower_trace(e.h, n, 300, out.ctypes.data_as(C.c_void_p), n, C.byref(wgs))
     t = out[:wgs.value].astype(np.int64)
@@ -33,5 +33,7 @@ for n in [int(x) for x in sys.argv[1:]] or [1024, 4096]:
     for x in range(8):
         m = t[:, 4] == x
         if m.any():
-            print(f"   XCC {x}: {m.sum():4d} workgroups, tower p50 {us(np.median(tower[m])):8.1f} max {us(tower[m].max()):8.1f}; first start {us(t[m, 0].min() - t0):6.1f} last end {us(t[m, 3].max() - t0):8.1f}")
+            ghz = np.median((t[m, 6] - t[m, 5]) / np.maximum(tower[m], 1)) * 0.1
+            print(f"   XCC {x}: {m.sum():4d} workgroups, tower p50 {us(np.median(tower[m])):8.1f} max {us(tower[m].max()):8.1f} us at {ghz:.3f} GHz = "
+                  f"{np.median(t[m, 6] - t[m, 5]) / 1e6:.3f} Mcycles; first start {us(t[m, 0].min() - t0):6.1f} last end {us(t[m, 3].max() - t0):8.1f}")
     e.close()
