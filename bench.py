@@ -36,7 +36,9 @@ sys.path.insert(0, ROOT)
 FLOP_PER_SIM = {20: 2 * 797_976_348, 5: 2 * 200_288_028}  # valid (un-padded) taps only
 PEAK_BF16 = 2.5e15   # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32 = 157.3e12  # fp32 vector/matrix
-EXTRA_CONFIGS = [(256, 100, 2), (2048, 400, 2)]   # BASELINE.json configs[1], configs[2] (games, sims/move, THREADS_PER_MCTS)
+# BASELINE.json configs[1], configs[2] (games, sims/move, THREADS_PER_MCTS), and configs[1] at -t 4: with 256 games the leaf
+# batch of a pass is games x THREADS_PER_MCTS, and 1024 leaf slots fill every CU with a 4-board tile
+EXTRA_CONFIGS = [(256, 100, 2), (2048, 400, 2), (256, 100, 4)]
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by tools/pmc_summary.py from rocprofv3 --pmc runs
 
 
