@@ -1263,7 +1263,9 @@ extern "C" int azr_selfplay_run(azr_engine* h, int passes)
     ENTER(h);
     if (h->mode != 2) { h->err = "azr_selfplay_run: call azr_selfplay_start first"; return AZR_E_STATE; }
     if (!h->weights_set) { h->err = "azr_selfplay_run: no weights"; return AZR_E_STATE; }
-    const int PROF_MAX = 512;  // launches timed with events (spread over the run)
+    // launches timed with HIP events, spread evenly over the run.  A sample, not every pass: an event is a marker packet the
+    // queue has to retire, and five of them per pass cost ~18 us of a 1.1 ms pass.
+    const int PROF_MAX = 24;
     const int nprof = std::min(passes, PROF_MAX);
     while ((int)h->ev.size() < 5 * PROF_MAX) {
         hipEvent_t e;

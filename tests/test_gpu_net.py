@@ -126,11 +126,12 @@ def test_bf16_tower_at_depth_matches_fp32_oracle(orc, n):
     eng.close()
 
 
-def test_tile_shapes_agree_bit_for_bit(monkeypatch):
+@pytest.mark.parametrize("blocks", [20, 1, 2])
+def test_tile_shapes_agree_bit_for_bit(monkeypatch, blocks):
     """the 4-boards-per-workgroup single-buffer kernel (azr_tower_sb.hip) and the 1..3-board kernels compute the same
     bits: same k order, same fp32 epilogue, same rounding points (AZR_TOWER_SB is read once, at engine creation)"""
     P = pkg()
-    blocks, n = 20, 1024
+    n = 1024
     g = np.unique(np.load(os.path.join(T.GOLDEN, "encode.npz"))["in88"], axis=0)
     x = g[np.linspace(0, len(g) - 1, n).astype(int)].copy()
     flat = T.make_net_flat(blocks, seed=3, perturb_bn=True)
@@ -143,6 +144,8 @@ def test_tile_shapes_agree_bit_for_bit(monkeypatch):
         # a ragged batch (last workgroup partly filled) and a tiny one take the same values
         p7, v7 = eng.predict(x[:1023])
         assert (p7.view(np.uint32) == out[mode][0][:1023].view(np.uint32)).all() and (v7 == out[mode][1][:1023]).all()
+        p5, v5 = eng.predict(x[:5])
+        assert (p5.view(np.uint32) == out[mode][0][:5].view(np.uint32)).all() and (v5 == out[mode][1][:5]).all()
         eng.close()
     assert (out["0"][0].view(np.uint32) == out["2"][0].view(np.uint32)).all()
     assert (out["0"][1].view(np.uint32) == out["2"][1].view(np.uint32)).all()
