@@ -1569,6 +1569,7 @@ extern "C" int azr_nn_train_batch(azr_engine* h, const void* rec265_host, int n,
     if (!rec265_host || n < 2) { h->err = "azr_nn_train_batch: need a minibatch of at least 2 records"; return AZR_E_INVALID_ARGUMENT; }
     TRY(ctx_ensure(h, n));
     TrainCtx* c = ctx_of(h);
+    c->world = 1; c->rank = 0; c->ar = nullptr; c->ar_ctx = nullptr;   // (a data-parallel call that failed half-way must not linger)
     TRY(upload_records(h, c, rec265_host, (size_t)n));
     std::vector<int> id(n);
     for (int i = 0; i < n; i++) id[i] = i;
