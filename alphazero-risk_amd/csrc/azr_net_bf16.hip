@@ -636,9 +636,9 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
     // sb_mode 0 = never, 1 = when it is the faster plan, 2 = whenever the batch has 4 boards per CU or more
     if ((x->sb_mode == 1 && n >= 1024) || (x->sb_mode == 2 && n >= 4)) {
         const int wgs4 = (n + 3) / 4, rounds4 = (wgs4 + 255) / 256;
-        // measured launch times per 256-workgroup round, ms: 1 / 2 / 3 boards 0.48 / 0.75 / 0.97 (round 1), 4 boards: T4
+        // measured launch times per 256-workgroup round, ms: 1 / 2 / 3 boards 0.48 / 0.75 / 0.97, 4 boards (k_tower_sb4) 1.10
         static const float t[4] = {0.0f, 0.48f, 0.75f, 0.97f};
-        const float T4 = 1.15f;
+        const float T4 = 1.10f;
         float old_ms = 0.0f;
         {   // the mixed launch above: every CU slot runs `rounds` workgroups, n_full of them with nb boards
             const int big = n_full, small = wgs - n_full;   // workgroups of nb and nb - 1 boards

@@ -56,3 +56,20 @@ def test_two_rank_bench_on_one_gpu():
     o1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     assert o1["n_gpus"] == 1 and o1["exchange"]["records_gathered"] > 0
     assert out["roofline"]["leaf_slots_per_launch"] == o1["roofline"]["leaf_slots_per_launch"] == 64
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_as_the_driver_launches_it():
+    """the driver's own form for N > 1: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N (gloo here:
+    the two ranks share this box's one card)"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), BENCH, "--gpus", "2"] + SMALL
+    r = subprocess.run(cmd, env=_env(AZR_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                      # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["exchange"]["records_gathered"] > out["exchange"]["records_this_rank"] > 0
+    assert "extra_configs" not in out and "cpu_baseline" not in out      # N > 1: the headline only
