@@ -539,6 +539,11 @@ __global__ __launch_bounds__(64) void k_tree_step(Dev E)
     if (root_dirty) ws_store(root, E.state + (size_t)g * GREC);
     ctl_store(c, &E.ctl[g]);
     flush_counters(E, c, k);
+    // self-play tail (quota mode, slots going idle): the net of this pass runs on the waiting leaf slots only
+    if (SELFPLAY && E.sp_compact && c.pending && lane_id() < (uint32_t)E.T && ((c.pending >> lane_id()) & 1u)) {
+        const int at = atomicAdd(&E.leaf_count[0], 1);
+        E.leaf_list[at] = g * E.T + (int)lane_id();
+    }
 }
 
 // ================================================================================================
@@ -920,6 +925,8 @@ static int engine_init(azr_engine* h, const azr_settings* s)
     HIPCHK(h, dmalloc(&d.active, 1));
     HIPCHK(h, dmalloc(&d.arena_taken, 1));
     HIPCHK(h, dmalloc(&d.sp_started, 1));
+    HIPCHK(h, dmalloc(&d.leaf_list, 2 * GT));      // leaf slots waiting for net A / net B (two-net arena; self-play tail uses [0])
+    HIPCHK(h, dmalloc(&d.leaf_count, (size_t)2));
     HIPCHK(h, dmalloc(&d.arena_res, 8));
     HIPCHK(h, dmalloc(&d.prev_start, G * GREC));
     HIPCHK(h, dmalloc(&d.script, G * 2 * 32));
@@ -1235,6 +1242,8 @@ static int selfplay_start(azr_engine* h, uint32_t base_seed, unsigned long long 
 {
     h->d.base_seed = base_seed;
     h->d.sp_quota = quota;
+    h->d.sp_compact = 0;
+    h->sp_tail = false;
     h->mode = 2;
     const unsigned long long started = quota ? std::min<unsigned long long>(quota, (unsigned long long)h->d.G) : 0ull;
     HIPCHK(h, hipMemcpyAsync(h->d.sp_started, &started, sizeof started, hipMemcpyHostToDevice, h->stream));
@@ -1274,14 +1283,37 @@ extern "C" int azr_selfplay_run(azr_engine* h, int passes)
     }
     const int stride = passes > nprof ? passes / nprof : 1;
     int k = 0;
+    const int GT = h->d.G * h->d.T;
     for (int p = 0; p < passes; p++) {
+        // Quota mode (azr_selfplay_start_games): once every game has been started the slots go idle one by one.  From then
+        // on a pass evaluates the waiting leaf slots only (listed by the tree step, one count read-back per pass) and the
+        // tile plan follows the shrinking batch — a launch over 1024 mostly idle slots costs as much as a full one.
+        if (h->d.sp_quota && !h->sp_tail && p % 32 == 0) {
+            unsigned long long started = 0;
+            D2H(h, &started, h->d.sp_started, sizeof started);
+            SYNC(h);
+            h->sp_tail = started >= h->d.sp_quota;
+            h->d.sp_compact = h->sp_tail ? 1 : 0;
+        }
+        int n_eval = GT;
+        const int* map = nullptr;
         const bool prof = (p % stride == 0) && k < nprof;
+        if (h->sp_tail) HIPCHK(h, hipMemsetAsync(h->d.leaf_count, 0, sizeof(int), h->stream));
         if (prof) HIPCHK(h, hipEventRecord(h->ev[3 * k + 0], h->stream));
         LAUNCH(h, k_tree_step<true>, h->d);
         if (prof) HIPCHK(h, hipEventRecord(h->ev[3 * k + 1], h->stream));
+        if (h->sp_tail) {
+            D2H(h, &n_eval, h->d.leaf_count, sizeof(int));
+            SYNC(h);
+            map = h->d.leaf_list;
+            if (n_eval == 0) {   // nothing waits for the net: every game of the quota is over
+                if (prof) { HIPCHK(h, hipEventRecord(h->ev[3 * k + 2], h->stream)); h->pe_tower0 = h->pe_tower1 = nullptr; }
+                break;
+            }
+        }
         h->pe_tower0 = prof ? h->ev[3 * PROF_MAX + 2 * k] : nullptr;
         h->pe_tower1 = prof ? h->ev[3 * PROF_MAX + 2 * k + 1] : nullptr;
-        int rc = net_forward(h, h->d.leaf_in, LEAF_STRIDE, h->d.G * h->d.T, h->d.net_pi, h->d.net_v);
+        int rc = net_forward_ex(h, h->d.leaf_in, LEAF_STRIDE, n_eval, h->d.net_pi, h->d.net_v, map, h->stream);
         h->pe_tower0 = h->pe_tower1 = nullptr;
         if (rc) return rc;
         if (prof) { HIPCHK(h, hipEventRecord(h->ev[3 * k + 2], h->stream)); k++; }
@@ -1473,8 +1505,6 @@ extern "C" int azr_arena_set_opponent_net(azr_engine* h, azr_engine* other)
         HIPCHK(h, dmalloc(&tb2, G * d.H)); h->tree2[3] = tb2;
         HIPCHK(h, dmalloc(&f2, G * C)); h->tree2[4] = f2;
         HIPCHK(h, dmalloc(&tc2, G * 4)); h->tree2[5] = tc2;
-        HIPCHK(h, dmalloc(&d.leaf_list, 2 * G * d.T));
-        HIPCHK(h, dmalloc(&d.leaf_count, (size_t)2));
         HIPCHK(h, hipMemsetAsync(t2, 0, G * C * sizeof(uint32_t), h->stream));
         HIPCHK(h, hipMemsetAsync(tb2, 0, G * d.H * sizeof(uint32_t), h->stream));
         HIPCHK(h, hipMemsetAsync(tc2, 0, G * 4 * sizeof(uint32_t), h->stream));

@@ -46,6 +46,8 @@ struct Dev {
     uint32_t base_seed;
     unsigned long long sp_quota;      // self-play quota mode: games to start in all (0 = unlimited)
     unsigned long long* sp_started;   // ... and the ticket counter
+    int sp_compact;                   // self-play tail: the tree step lists the waiting leaf slots (leaf_list[0], leaf_count[0]) and
+                                      // the net runs on that list only
     // arena (GameGroup::playGames, game/game.cpp:277-312)
     int kind0, kind1;          // AZR_PLAYER_* of player index 0 / 1
     int arena_total;           // Counter::count
@@ -110,6 +112,7 @@ struct azr_engine {
     bool weights_set;
     void* tree2[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // nodes2, touch2, nhash2, table2, freel2, tctl2
     azr_engine* opponent = nullptr;  // handle whose network plays AZR_PLAYER_ALPHAZERO_B (azr_arena_set_opponent_net)
+    bool sp_tail = false;         // quota self-play: no game is left to start, slots go idle -> compacted net batches
     void* train = nullptr;        // azr_train.hip: optimiser state + activation slabs, created by the first azr_nn_train*
 };
 
