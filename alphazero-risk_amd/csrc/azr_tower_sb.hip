@@ -202,7 +202,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb4(const uint8_t* __restr
         diag[8 + 8 * (size_t)blockIdx.x + 4] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (3 << 11)) & 15u;
     }
 
-    // ---- weight ring: the first RING k-steps of layer 0 fly while the tables and the stem are built
+    // ---- weight ring: the first RING - 1 k-steps of layer 0 fly while the tables and the stem are built
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(tower_wp), (short)0, 0x7fffffff, 0x00020000);
     const uint32_t loff = (uint32_t)((wave * NT) * 64 + lane) * 16u;   // this lane's fragment bytes inside a k-step block
     uint32_t wk = 0;                                                     // byte offset of the current k-step (wave-uniform)

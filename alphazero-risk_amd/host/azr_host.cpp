@@ -4,6 +4,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <iostream>
@@ -550,8 +551,13 @@ std::ostream& operator<<(std::ostream& os, const GameResults& gr)  // game.cpp:2
               << gr.players[1].winAndStartedGame;
 }
 
+// every playGames call of a run plays other games: the reference draws from its process-global RNG, here a call counter
+// moves the base seed (a compare / benchmark round must not replay the previous iteration's deals)
+static std::atomic<uint32_t> arenaCallCounter{0};
+
 GameResults GameGroup::playGames(AlphaZeroPlayerGroup& pg1, AlphaZeroPlayerGroup& pg2, int games, NNTrainDataStorage* tds)
 {
+    const uint32_t arenaCallsBase = ++arenaCallCounter;
     // Device-resident arena: pg1's engine of GPU i runs the G slots, pg2's network of the same GPU plays
     // AZR_PLAYER_ALPHAZERO_B (own tree per slot, evaluated on its own leaves).  Every slot is one of the reference's
     // threadPlayGame threads taking mirrored pairs from the shared counter (game.cpp:238-254).
@@ -571,7 +577,7 @@ GameResults GameGroup::playGames(AlphaZeroPlayerGroup& pg1, AlphaZeroPlayerGroup
             e.check(azr_arena_set_opponent_net(e.h, o.h), "arena_set_opponent_net");
             e.check(azr_arena_collect_samples(e.h, tds ? 1 : 0), "arena_collect_samples");
             e.check(azr_arena_start(e.h, AZR_PLAYER_ALPHAZERO, AZR_PLAYER_ALPHAZERO_B, share, 0, SETTINGS.MIRROR_GAMES,
-                                    SETTINGS.BASE_SEED + 7919u + (uint32_t)i * (1u << 24)), "arena_start");
+                                    SETTINGS.BASE_SEED + 7919u * arenaCallsBase + (uint32_t)i * (1u << 24)), "arena_start");
             int fin = 0;
             std::vector<uint8_t> buf;
             while (!fin) {
@@ -606,6 +612,7 @@ GameResults GameGroup::playGames(AlphaZeroPlayerGroup& pg1, AlphaZeroPlayerGroup
 
 GameResults GameGroup::playGames(AlphaZeroPlayerGroup& pg1, int otherKind, int games)
 {
+    const uint32_t arenaCallsBase = ++arenaCallCounter;
     const int P = (int)pg1.nnGroup->size();
     printf("Playing games %d\n", games);
     std::vector<azr_game_results> res(P);
@@ -618,7 +625,7 @@ GameResults GameGroup::playGames(AlphaZeroPlayerGroup& pg1, int otherKind, int g
             memset(&res[i], 0, sizeof res[i]);
             if (share == 0) return;
             e.check(azr_arena_start(e.h, AZR_PLAYER_ALPHAZERO, otherKind, share, 0, SETTINGS.MIRROR_GAMES,
-                                    SETTINGS.BASE_SEED + 104729u + (uint32_t)i * (1u << 24)), "arena_start");
+                                    SETTINGS.BASE_SEED + 104729u * arenaCallsBase + (uint32_t)i * (1u << 24)), "arena_start");
             int fin = 0;
             while (!fin) e.check(azr_arena_run(e.h, 4 * (SETTINGS.MCTS_SIMULATIONS + 2), &fin), "arena_run");
             e.check(azr_arena_results(e.h, &res[i]), "arena_results");

@@ -236,9 +236,9 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
             gen.set_weights(new.get_weights())   # generateGroup->loadCheckpoint(best): every rank already holds them
             t_bench = time.time()
             r = run_arena(gen, P.PLAYER_ALPHAZERO, P.PLAYER_RANDOM, 2 * shard_mod.split_count(5, world, rank), True,
-                          shard_mod.rank_base_seed(a.seed + 11, rank))
+                          shard_mod.rank_base_seed(a.seed + 11 + 104729 * (it + 1), rank))
             s = run_arena(gen, P.PLAYER_ALPHAZERO, P.PLAYER_SCRIPT, 2 * shard_mod.split_count(50, world, rank), True,
-                          shard_mod.rank_base_seed(a.seed + 13, rank))
+                          shard_mod.rank_base_seed(a.seed + 13 + 15485863 * (it + 1), rank))
             if dist is not None:
                 r, s = reduce_results(r, dist, cdev), reduce_results(s, dist, cdev)
             bench_log.write(benchmark_line(it, r, s)); bench_log.flush()
