@@ -634,7 +634,7 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
     else nb += 1;
     // 4 boards per workgroup in one LDS image (azr_tower_sb.hip) when that needs fewer passes over the weight stream:
     // sb_mode 0 = never, 1 = when it is the faster plan, 2 = whenever the batch has 4 boards per CU or more
-    if ((x->sb_mode == 1 && n >= 1024) || (x->sb_mode == 2 && n >= 4)) {
+    if ((x->sb_mode == 1 && n > 768) || (x->sb_mode == 2 && n >= 4)) {   // (up to 768 boards one round of 1..3-board tiles is the cheaper plan)
         const int wgs4 = (n + 3) / 4, rounds4 = (wgs4 + 255) / 256;
         // measured launch times per 256-workgroup round, ms: 1 / 2 / 3 boards 0.48 / 0.75 / 0.97, 4 boards (k_tower_sb4) 1.10
         static const float t[4] = {0.0f, 0.48f, 0.75f, 0.97f};
