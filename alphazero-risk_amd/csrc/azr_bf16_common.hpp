@@ -39,7 +39,7 @@ __device__ __forceinline__ float plane_value(const uint8_t* in88, int pos, int c
 {
     const uint32_t b = in88[pos];
     const int army = b & 63, owner = b >> 6, cur = in88[42], enemy = cur == 0 ? 1 : 0;
-    const float fa = (float)army / 32.0f;
+    const float fa = (float)army * 0.03125f;   // = army / 32 exactly (a power of two), without the correctly-rounded division sequence
     const float* f = reinterpret_cast<const float*>(in88 + 48);
     switch (c) {
     case 0: return owner == cur ? fa : 0.0f;
