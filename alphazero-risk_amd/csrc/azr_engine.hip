@@ -697,13 +697,17 @@ __global__ __launch_bounds__(64) void k_arena_step(Dev E)
             c.pending = 0; c.search_active = 0; c.turn_started = 0;
         }
     }
-    if (two) {
-        if (lane_id() == 0) { uint32_t* d2 = E.tctl2 + (size_t)g * 4; d2[0] = x2.search_id; d2[1] = x2.nfree; d2[2] = x2.hiwater; }
-        // hand every waiting leaf to the network of the player that is searching
-        if (c.pending && lane_id() < (uint32_t)E.T && ((c.pending >> lane_id()) & 1u)) {
-            const int at = atomicAdd(&E.leaf_count[c.search_tree], 1);
-            E.leaf_list[(size_t)c.search_tree * E.G * E.T + at] = g * E.T + (int)lane_id();
-        }
+    if (two && lane_id() == 0) { uint32_t* d2 = E.tctl2 + (size_t)g * 4; d2[0] = x2.search_id; d2[1] = x2.nfree; d2[2] = x2.hiwater; }
+    // hand every waiting leaf to the network of the player that is searching (list 0 when there is one network): a pass
+    // evaluates the listed slots only — most slots of an arena idle (scripted players' turns, finished quotas)
+    if (c.pending) {
+        const uint32_t tree = two ? c.search_tree : 0u;
+        int base = 0;
+        if (lane_id() == 0) base = atomicAdd(&E.leaf_count[tree], (int)__builtin_popcount(c.pending));   // one atomic per slot
+        base = (int)rfl((uint32_t)base);
+        const uint32_t l = lane_id();
+        if (l < (uint32_t)E.T && ((c.pending >> l) & 1u))
+            E.leaf_list[(size_t)tree * E.G * E.T + base + (int)__builtin_popcount(c.pending & ((1u << l) - 1u))] = g * E.T + (int)l;
     }
     c.rng = root.rng;
     ws_store(root, E.state + (size_t)g * GREC);
@@ -1481,9 +1485,23 @@ extern "C" int azr_arena_run(azr_engine* h, int passes, int* finished_out)
         }
     } else
     for (int p = 0; p < passes; p++) {
+        if (needs_net) HIPCHK(h, hipMemsetAsync(h->d.leaf_count, 0, sizeof(int), h->stream));
         LAUNCH(h, k_arena_step, h->d);
-        if (needs_net) {
-            int rc = net_forward(h, h->d.leaf_in, LEAF_STRIDE, h->d.G * h->d.T, h->d.net_pi, h->d.net_v);
+        if (needs_net) {   // one network: evaluate the waiting leaf slots only (one count read-back per pass)
+            int cnt = 0;
+            D2H(h, &cnt, h->d.leaf_count, sizeof cnt);
+            SYNC(h);
+            if (cnt == 0) {
+                // nobody waits for the net: either every slot is idle (quota exhausted) or only scripted players moved
+                std::vector<uint32_t> st0(h->d.G);
+                HIPCHK(h, hipMemcpy2DAsync(st0.data(), 4, &h->d.ctl[0].arena_state, sizeof(Ctl), 4, h->d.G, hipMemcpyDeviceToHost, h->stream));
+                SYNC(h);
+                bool all_idle = true;
+                for (uint32_t v : st0) all_idle = all_idle && v == 2;
+                if (all_idle) break;
+                continue;
+            }
+            int rc = net_forward_ex(h, h->d.leaf_in, LEAF_STRIDE, cnt, h->d.net_pi, h->d.net_v, h->d.leaf_list, h->stream);
             if (rc) return rc;
         }
     }
