@@ -60,7 +60,7 @@ def test_learn_mode_generates_reference_format_samples(exe, tmp_path):
     for f in ("log/azr-improvement-log.txt", "log/azr-benchmark-log.txt", "log/azr-nn-training-log.txt",
               "checkpoints/best-checkpoint.bin", "checkpoints/checkpoint-iter-0.bin", "checkpoints/temp.bin"):
         assert os.path.getsize(tmp_path / f) > 0, f
-    from test_log_grammar import check   # the reference's own grammar (tests/golden/ref_logs) and log_chart.py's parsing
+    from test_log_grammar import check   # the reference's own grammar (tests/golden/ref_logs.json) and log_chart.py's parsing
     assert len(check("improvement", open(tmp_path / "log" / "azr-improvement-log.txt").read())) == 1
     assert len(check("benchmark", open(tmp_path / "log" / "azr-benchmark-log.txt").read())) == 1
     assert [len(r) for r in check("nn", open(tmp_path / "log" / "azr-nn-training-log.txt").read())] == [4]

@@ -70,7 +70,7 @@ def test_one_learn_iteration_end_to_end(tmp_path):
               "checkpoints/latest-checkpoint.bin", "checkpoints/best-checkpoint.bin", "checkpoints/checkpoint-iter-0.bin",
               "data/training_samples.bin"):
         assert os.path.getsize(tmp_path / f) > 0, f
-    from test_log_grammar import check   # the reference's own grammar (tests/golden/ref_logs) and log_chart.py's parsing
+    from test_log_grammar import check   # the reference's own grammar (tests/golden/ref_logs.json) and log_chart.py's parsing
     imp_rows = check("improvement", open(tmp_path / "log/azr-improvement-log.txt").read())
     ben_rows = check("benchmark", open(tmp_path / "log/azr-benchmark-log.txt").read())
     nn_rows = check("nn", open(tmp_path / "log/azr-nn-training-log.txt").read())

@@ -1,5 +1,5 @@
 """CPU: the three log files of the learn loop keep the reference's grammar, so python/src/log_chart.py
-keeps reading them.  Fixtures: the authors' own log files (tests/golden/ref_logs/, copied output data).  The grammar is
+keeps reading them.  Fixtures: the authors' own log files (tests/golden/ref_logs.json, output data of their runs).  The grammar is
 written once below, checked against every line the reference ever wrote, then against the lines the Python learn loop
 (alphazero-risk_amd/learn.py) and the C++ host (host/azr_host.cpp through tests/helpers/samples_probe.cpp) format —
 and, on the GPU box, against the files an end-to-end iteration leaves behind (tests/test_learn.py, test_host_cli.py)."""
@@ -15,7 +15,17 @@ import pytest
 import azr_testlib as T
 from gpu_common import ROOT
 
-LOGS = os.path.join(T.GOLDEN, "ref_logs")
+import json
+
+REF = json.load(open(os.path.join(T.GOLDEN, "ref_logs.json")))   # the authors' own log files (tests/golden/make_logs_golden.py)
+
+
+def ref_text(kind):
+    return REF[kind]["text"]
+
+
+def ref_first_line(kind):
+    return REF[kind]["text"].split("\n")[0] + "\n"
 PLAYER = r"\d+/\d+"
 GR = rf"\d+, {PLAYER}, {PLAYER}"                       # operator<<(GameResults), game.cpp:227-235: draw, W/Wstart, W/Wstart
 IMPROVEMENT = re.compile(rf"^\d+,{GR}$")                # alphazero_trainer.cpp:163
@@ -52,22 +62,22 @@ def check(kind, text, complete=True):
 
 
 def test_the_grammar_is_the_references():
-    imp = check("improvement", open(os.path.join(LOGS, "azr-improvement-log.txt")).read())
+    imp = check("improvement", ref_text("improvement"))
     assert len(imp) == 65 and imp[0] == (0, 53, 145, 33, 58, 4)
-    ben = check("benchmark", open(os.path.join(LOGS, "azr-benchmark-log.txt")).read())
+    ben = check("benchmark", ref_text("benchmark"))
     assert len(ben) == 13 and ben[0][:3] == (0, 1, 0) and all(sum(r[1:2]) + r[3] + r[5] == 10 for r in ben)   # 10 games vs Random
-    nn = check("nn", open(os.path.join(LOGS, "azr-nn-training-log.txt")).read(), complete=False)
+    nn = check("nn", ref_text("nn"), complete=False)
     assert len(nn) == 66 and all(len(r) % 2 == 0 for r in nn) and nn[0][:2] == (3.49221, 0.632382)
 
 
 def test_python_learn_loop_lines():
     L = importlib.import_module("alphazero-risk_amd.learn")
     gr = dict(count=250, draw=53, win=[145, 58], win_and_started=[33, 4])
-    assert L.improvement_line(0, gr) == open(os.path.join(LOGS, "azr-improvement-log.txt")).readline()   # the reference's first line
+    assert L.improvement_line(0, gr) == ref_first_line("improvement")   # the reference's first line
     r = dict(count=10, draw=1, win=[0, 9], win_and_started=[0, 4])
     s = dict(count=100, draw=0, win=[0, 100], win_and_started=[0, 50])
-    assert L.benchmark_line(0, r, s) == open(os.path.join(LOGS, "azr-benchmark-log.txt")).readline()
-    first = open(os.path.join(LOGS, "azr-nn-training-log.txt")).readline()
+    assert L.benchmark_line(0, r, s) == ref_first_line("benchmark")
+    first = ref_first_line("nn")
     vals = [float(x) for x in first.split(",")[:-1]]
     assert L.nn_training_line(list(zip(vals[0::2], vals[1::2]))) == first
     check("improvement", L.improvement_line(7, gr) + L.improvement_line(8, gr))
@@ -85,7 +95,7 @@ def test_cpp_host_lines(tmp_path):
                            os.path.join(host, "azr_host.o"), "-o", exe, "-L", csrc, "-lazr_hip", "-Wl,-rpath," + csrc])
     out = subprocess.run([exe, "loglines", "0", "53", "145", "33", "58", "4", "0", "0", "0", "100", "50", "3.49221"],
                          capture_output=True, text=True, check=True).stdout.split("\n")
-    assert out[0] + "\n" == open(os.path.join(LOGS, "azr-improvement-log.txt")).readline()
+    assert out[0] + "\n" == ref_first_line("improvement")
     check("improvement", out[0] + "\n")
     check("benchmark", out[1] + "\n")
     check("nn", out[2] + "\n")
