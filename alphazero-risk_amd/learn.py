@@ -261,7 +261,8 @@ def main():
     ap.add_argument("--tg", type=int, default=1000)       # TRAIN_ITERATION_GAMES
     ap.add_argument("--mcts", type=int, default=32)
     ap.add_argument("-t", type=int, default=2)            # THREADS_PER_MCTS
-    ap.add_argument("--gpu-games", type=int, default=256)
+    ap.add_argument("--gpu-games", type=int, default=512,
+                    help="concurrent games per GPU; 512 x THREADS_PER_MCTS 2 = 1024 leaf slots fill every CU with a 4-board tile")
     ap.add_argument("--blocks", type=int, default=20)
     ap.add_argument("-e", type=int, default=10)           # EPOCHS
     ap.add_argument("--bs", type=int, default=512)
