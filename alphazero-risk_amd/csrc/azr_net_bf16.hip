@@ -463,12 +463,25 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
         float* feat = reinterpret_cast<float*>(bufT);   // [NB][128]: 84 policy features, then 42 value features
         float* hid = feat + NB * 128;                   // [NB][256]
         float* logit = hid + NB * 256;                  // [NB][64]
+        // 1x1 convs (256 -> 2 policy + 1 value channel per cell): the three weight columns are staged in LDS (bufT is free;
+        // the dense scratch above takes its first NB * 1792 bytes) and the activations are read 8 channels at a time — the
+        // same fma chain over ci = 0..255 as ever, so the same bits (the fp32 path's k_heads and the 4-board kernel agree)
+        float* wl = reinterpret_cast<float*>(bufT + 8192);       // [3][256]
+        for (int i = tid; i < 3 * NF; i += THREADS) wl[i] = i < 2 * NF ? wpi[(i & (NF - 1)) * 2 + (i >> 8)] : wv[i - 2 * NF];
+        __syncthreads();
         for (int idx = tid; idx < NB * 126; idx += THREADS) {  // 42 cells x {pi0, pi1, v} per board
             const int bb = idx / 126, t = idx % 126, pos = t / 3, c = t % 3;
-            const uint16_t* x = reinterpret_cast<const uint16_t*>(bufX + rowof[bb * 42 + pos] * ROWB);
+            const s16x8* x8 = reinterpret_cast<const s16x8*>(bufX + rowof[bb * 42 + pos] * ROWB);
+            const float4* w4 = reinterpret_cast<const float4*>(wl + c * NF);
             float sacc = 0.0f;
-            if (c < 2) for (int ci = 0; ci < NF; ci++) sacc = fmaf(bf2f(x[ci]), wpi[ci * 2 + c], sacc);
-            else for (int ci = 0; ci < NF; ci++) sacc = fmaf(bf2f(x[ci]), wv[ci], sacc);
+            for (int q = 0; q < NF / 8; q++) {
+                const s16x8 xx = x8[q];
+                const float4 wa = w4[2 * q], wb = w4[2 * q + 1];
+                sacc = fmaf(bf2f((uint16_t)xx[0]), wa.x, sacc); sacc = fmaf(bf2f((uint16_t)xx[1]), wa.y, sacc);
+                sacc = fmaf(bf2f((uint16_t)xx[2]), wa.z, sacc); sacc = fmaf(bf2f((uint16_t)xx[3]), wa.w, sacc);
+                sacc = fmaf(bf2f((uint16_t)xx[4]), wb.x, sacc); sacc = fmaf(bf2f((uint16_t)xx[5]), wb.y, sacc);
+                sacc = fmaf(bf2f((uint16_t)xx[6]), wb.z, sacc); sacc = fmaf(bf2f((uint16_t)xx[7]), wb.w, sacc);
+            }
             const float* bnp = c < 2 ? bnpi : bnv;
             const int nc = c < 2 ? 2 : 1, kk = c < 2 ? c : 0;
             float y = (sacc - bnp[2 * nc + kk]) * (bnp[kk] / sqrtf(bnp[3 * nc + kk] + 1e-3f)) + bnp[nc + kk];
