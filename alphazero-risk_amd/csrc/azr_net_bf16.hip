@@ -645,20 +645,23 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
     if (nb == 0) { nb = 1; wgs = n_full = n; }          // fewer boards than CUs: one each
     else if (n_full == 0) n_full = W;                  // exact multiple: all workgroups carry nb
     else nb += 1;
-    // 4 boards per workgroup in one LDS image (azr_tower_sb.hip) when that needs fewer passes over the weight stream:
-    // sb_mode 0 = never, 1 = when it is the faster plan, 2 = whenever the batch has 4 boards per CU or more
-    if ((x->sb_mode == 1 && n > 768) || (x->sb_mode == 2 && n >= 4)) {   // (up to 768 boards one round of 1..3-board tiles is the cheaper plan)
-        const int wgs4 = (n + 3) / 4, rounds4 = (wgs4 + 255) / 256;
-        // measured launch times per 256-workgroup round, ms: 1 / 2 / 3 boards 0.48 / 0.75 / 0.97, 4 boards (k_tower_sb4) 1.10
-        static const float t[4] = {0.0f, 0.48f, 0.75f, 0.97f};
-        const float T4 = 1.10f;
-        float old_ms = 0.0f;
-        {   // the mixed launch above: every CU slot runs `rounds` workgroups, n_full of them with nb boards
-            const int big = n_full, small = wgs - n_full;   // workgroups of nb and nb - 1 boards
-            old_ms = ((float)big * t[nb] + (float)small * t[nb > 1 ? nb - 1 : 1]) / 256.0f;
+    // Single-image tiles (azr_tower_sb.hip) for 2, 3 or 4 boards per workgroup.  AZR_TOWER_SB: 0 = never (the two-image
+    // kernels only), 1 = plan (default), 2 / 3 / 4 = force the 4- / 2- / 3-board tile for every launch (tests, measurements).
+    {
+        int snb = x->sb_mode == 2 ? 4 : x->sb_mode == 3 ? 2 : x->sb_mode == 4 ? 3 : 0;
+        if (x->sb_mode == 1 && n > 256) {
+            // measured launch time of one 256-workgroup round, ms (tools/tower_time.py): 2 / 3 / 4 boards per workgroup.
+            // One workgroup per CU is resident, so a launch of w workgroups takes ceil(w / 256) rounds.
+            static const float T[5] = {0.0f, 0.0f, 0.61f, 0.80f, 1.05f};
+            float best = 0.0f;
+            for (int c = 4; c >= 2; c--) {
+                const int w = (n + c - 1) / c;
+                const float ms = (float)((w + 255) / 256) * T[c];
+                if (snb == 0 || ms < best) { snb = c; best = ms; }
+            }
         }
-        if (x->sb_mode == 2 || rounds4 * T4 < old_ms) {
-            int rc = tower_sb_launch(h, 4, wgs4, d_in88, in_stride, n, d_pi, d_v, d_map, st);
+        if (snb && n >= snb) {
+            int rc = tower_sb_launch(h, snb, (n + snb - 1) / snb, d_in88, in_stride, n, d_pi, d_v, d_map, st);
             if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
             return rc;
         }

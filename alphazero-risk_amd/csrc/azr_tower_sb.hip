@@ -45,43 +45,85 @@ using namespace azr;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 namespace {
-constexpr int NB = 4;                  // boards per workgroup
-constexpr int ROWS = 42 * NB;          // 168 board cells
-constexpr int MT = 11;                 // 16-row MFMA tiles (176 rows, 8 pad rows)
-constexpr int ZR = MT * 16;            // index of the shared zero row
 constexpr int NT = 4;                  // 16-channel column tiles per wave (4 waves x 64 channels)
 constexpr int WAVES = 4, THREADS = 256;
-constexpr int RING = 4;                // weight ring depth in k-steps
-// LDS map
-constexpr int BUF = (ZR + 1) * ROWB;                 // the activation image incl. its zero row            96 288 B
-constexpr int FEAT_OFF = BUF;                        // stem features [(ZR + 1)][16 bf16]                    5 664 B
-constexpr int HEAD_OFF = FEAT_OFF + (ZR + 1) * FROWB;  // heads scratch: NB x (128 + 256 + 64) floats       7 168 B
-constexpr int IN88_OFF = HEAD_OFF + NB * 448 * 4;    // NB x 96 B NNInputData images
-constexpr int ROWOF_OFF = IN88_OFF + NB * 96;        // u8 [176]: cell (board * 42 + pos) -> row
-constexpr int TAPROW_OFF = ROWOF_OFF + 176;          // u8 [10][ZR]: source row of (tap, row); tap 9 = all zero row
-constexpr int ROWCELL_OFF = TAPROW_OFF + 10 * ZR;    // u16 [ZR]: row -> y | x << 4 | board << 8, 0xffff = pad row
-constexpr int LDS_BYTES = ROWCELL_OFF + 2 * ZR;
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-static_assert(BUF % 16 == 0 && FEAT_OFF % 16 == 0 && HEAD_OFF % 16 == 0 && TAPROW_OFF % 4 == 0 && ROWCELL_OFF % 2 == 0, "alignment");
 
-// Row order.  tile 0 = 16 cells with y = 0, tile 1 = 16 cells y = 6, tile 2 = 16 cells x = 0 (y = 1..5), tile 3 = 16 cells
-// x = 5, tile 4 = the other 8 cells y = 0 + the 8 pad rows, tile 5 = the other 8 cells y = 6 + 4 cells x = 0 + 4 cells
-// x = 5, tiles 6..10 = the 80 interior cells.  Taps that leave the board from a tile's edge are skipped for that tile.
-__device__ __forceinline__ int row_of4(int b, int pos)
+// Geometry of a workgroup of NB boards (NB = 4: the product tile; NB = 2: the tile for 257..512 boards per launch).
+template <int NB_>
+struct SB {
+    static constexpr int NB = NB_;                       // boards per workgroup
+    static constexpr int ROWS = 42 * NB;                 // board cells
+    static constexpr int MT = (ROWS + 15) / 16;          // 16-row MFMA tiles: 11 (8 pad rows) / 6 (12 pad rows)
+    static constexpr int ZR = MT * 16;                   // index of the shared zero row
+    static constexpr int RING = 4;                         // weight ring depth in k-steps (72 = 0 mod RING)
+    // LDS map
+    static constexpr int BUF = (ZR + 1) * ROWB;                 // the activation image incl. its zero row     96 288 B at NB = 4
+    static constexpr int FEAT_OFF = BUF;                        // stem features [(ZR + 1)][16 bf16]             5 664 B
+    static constexpr int HEAD_OFF = FEAT_OFF + (ZR + 1) * FROWB;  // heads scratch: NB x (128 + 256 + 64) floats 7 168 B
+    static constexpr int IN88_OFF = HEAD_OFF + NB * 448 * 4;    // NB x 96 B NNInputData images
+    static constexpr int ROWOF_OFF = IN88_OFF + NB * 96;        // u8 [ZR]: cell (board * 42 + pos) -> row
+    static constexpr int TAPROW_OFF = ROWOF_OFF + ZR;           // u8 [10][ZR]: source row of (tap, row); tap 9 = all zero row
+    static constexpr int ROWCELL_OFF = TAPROW_OFF + 10 * ZR;    // u16 [ZR]: row -> y | x << 4 | board << 8, 0xffff = pad row
+    static constexpr int LDS_BYTES = ROWCELL_OFF + 2 * ZR;
+    static_assert(NB >= 2 && NB <= 4, "tile shapes");
+    static_assert(72 % RING == 0 && RING <= MAX_RING, "ring depth");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(BUF % 16 == 0 && FEAT_OFF % 16 == 0 && HEAD_OFF % 16 == 0 && TAPROW_OFF % 4 == 0 && ROWCELL_OFF % 2 == 0, "alignment");
+    static_assert(3 * NF * 4 <= (ZR + 1) * FROWB, "the heads stage 3 x 256 floats in the stem feature image");
+};
+
+// Row order = border classes, corners counted with the COLUMN classes: a cell with x = 0 has no in-board source under the
+// three taps with dx = -1 whatever its y, so all 7 x = 0 cells of a board (corners included) share tiles, likewise x = 5;
+// the y = 0 / y = 6 classes are the 4 non-corner cells.  Pad rows (no cell: zero under every tap) top up class tiles.
+//   NB = 4 (176 rows):  tile 0 = 16 cells x=0 | 1 = 16 cells x=5 | 2 = the other 12 x=0 + 4 pads | 3 = the other 12 x=5 + 4 pads
+//                       | 4 = 16 cells y=0 | 5 = 16 cells y=6 | 6..10 = the 80 interior cells          => 18 of 99 tile-taps skipped
+//   NB = 3 (128 rows):  the corners go where they complete a tile: tile 0 = 16 of the 18 cells y=0 (all but board 0's corners)
+//                       | 1 = 16 of the 18 cells y=6 | 2 = the 15 cells x=0, y=1..5 + board 0's (0,0) | 3 = same for x=5 with (5,0)
+//                       | 4..7 = board 0's (0,6) and (5,6), the 60 interior cells, 2 pads              => 12 of 72
+//   NB = 2 (96 rows):   tile 0 = 14 cells x=0 + 2 pads | 1 = 14 cells x=5 + 2 pads | 2 = 8 cells y=0 + 8 pads
+//                       | 3 = 8 cells y=6 + 8 interior | 4, 5 = interior                               =>  9 of 54
+template <int NB>
+__device__ __forceinline__ int row_of(int b, int pos)
 {
     const int y = pos / 6, x = pos - y * 6;
-    if (y == 0) { const int q = b * 6 + x; return q < 16 ? q : 64 + (q - 16); }
-    if (y == 6) { const int q = b * 6 + x; return q < 16 ? 16 + q : 80 + (q - 16); }
-    if (x == 0) { const int q = b * 5 + (y - 1); return q < 16 ? 32 + q : 88 + (q - 16); }
-    if (x == 5) { const int q = b * 5 + (y - 1); return q < 16 ? 48 + q : 92 + (q - 16); }
-    return 96 + b * 20 + (y - 1) * 4 + (x - 1);
+    if (NB == 4) {
+        if (x == 0) { const int q = b * 7 + y; return q < 16 ? q : 32 + (q - 16); }
+        if (x == 5) { const int q = b * 7 + y; return q < 16 ? 16 + q : 48 + (q - 16); }
+        if (y == 0) return 64 + b * 4 + (x - 1);
+        if (y == 6) return 80 + b * 4 + (x - 1);
+        return 96 + b * 20 + (y - 1) * 4 + (x - 1);
+    } else if (NB == 3) {
+        const bool corner0 = b == 0 && (x == 0 || x == 5);          // board 0's corners complete the column tiles
+        if (y == 0) return corner0 ? (x == 0 ? 47 : 63) : (b == 0 ? x - 1 : 4 + (b - 1) * 6 + x);
+        if (y == 6) return corner0 ? (x == 0 ? 64 : 65) : 16 + (b == 0 ? x - 1 : 4 + (b - 1) * 6 + x);
+        if (x == 0) return 32 + b * 5 + (y - 1);
+        if (x == 5) return 48 + b * 5 + (y - 1);
+        return 66 + b * 20 + (y - 1) * 4 + (x - 1);
+    } else {
+        if (x == 0) return b * 7 + y;
+        if (x == 5) return 16 + b * 7 + y;
+        if (y == 0) return 32 + b * 4 + (x - 1);
+        if (y == 6) return 48 + b * 4 + (x - 1);
+        return 56 + b * 20 + (y - 1) * 4 + (x - 1);
+    }
 }
 // bit mt set = tile mt has no in-board source cell under this tap (tap 9 = "no tap": everything skipped)
-__host__ __device__ constexpr uint32_t skip_mask4(int tap)
+template <int NB>
+__host__ __device__ constexpr uint32_t skip_mask(int tap)
 {
     if (tap > 8) return 0xffffffffu;
     const int ty = tap / 3, tx = tap - 3 * ty;
-    return (ty == 0 ? 0x11u : ty == 2 ? 0x2u : 0u) | (tx == 0 ? 0x4u : tx == 2 ? 0x8u : 0u);
+    if (NB == 4) return (tx == 0 ? 0x5u : tx == 2 ? 0xAu : 0u) | (ty == 0 ? 0x10u : ty == 2 ? 0x20u : 0u);
+    if (NB == 3) return (ty == 0 ? 0x1u : ty == 2 ? 0x2u : 0u) | (tx == 0 ? 0x4u : tx == 2 ? 0x8u : 0u);
+    return (tx == 0 ? 0x1u : tx == 2 ? 0x2u : 0u) | (ty == 0 ? 0x4u : 0u);
+}
+// first pad lane (fragment column) of tile mt; 16 = the tile has no pad rows
+template <int NB>
+__host__ __device__ constexpr int pad_from(int mt)
+{
+    if (NB == 4) return (mt == 2 || mt == 3) ? 12 : 16;
+    if (NB == 3) return mt == 7 ? 14 : 16;
+    return mt < 2 ? 14 : mt == 2 ? 8 : 16;
 }
 
 // s_waitcnt lgkmcnt(N) alone (vmcnt / expcnt untouched)
@@ -132,12 +174,13 @@ __device__ __forceinline__ uint2 bn_relu_pack(const f32x4& acc, const float4& s,
 //                  fragment for the next k-step
 // The compiler's own waitcnt insertion still runs afterwards and stays the safety net: an explicit wait only moves a wait
 // to an earlier, cheaper place.
-template <int TAP>
-__device__ __forceinline__ void conv_tap4(const uint8_t* bufX, const uint8_t* tr_c, uint32_t g16, const __amdgpu_buffer_rsrc_t wsrc,
-                                          uint32_t loff, uint32_t& wk, u32x4 (&bq)[RING][NT], f32x4 (&acc)[MT][NT], s16x8 (&a)[MT],
-                                          uint32_t (&ap)[MT])
+template <int NB, int TAP>
+__device__ __forceinline__ void conv_tap(const uint8_t* bufX, const uint8_t* tr_c, uint32_t g16, const __amdgpu_buffer_rsrc_t wsrc,
+                                         uint32_t loff, uint32_t& wk, u32x4 (&bq)[SB<NB>::RING][NT], f32x4 (&acc)[SB<NB>::MT][NT],
+                                         s16x8 (&a)[SB<NB>::MT], uint32_t (&ap)[SB<NB>::MT])
 {
-    constexpr uint32_t sk = skip_mask4(TAP), skn = skip_mask4(TAP + 1);
+    constexpr int MT = SB<NB>::MT, ZR = SB<NB>::ZR, RING = SB<NB>::RING;
+    constexpr uint32_t sk = skip_mask<NB>(TAP), skn = skip_mask<NB>(TAP + 1);
     constexpr int active = MT - __builtin_popcount(sk & ((1u << MT) - 1u));   // tiles that run this tap
     uint32_t np[MT];
 #pragma unroll
@@ -148,7 +191,10 @@ __device__ __forceinline__ void conv_tap4(const uint8_t* bufX, const uint8_t* tr
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) np[mt] = (uint32_t)tr_c[(TAP + 1) * ZR + mt * 16] * ROWB + g16;
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * NT));              // vmcnt(8); lgkmcnt / expcnt untouched
+        {   // vmcnt((RING - 2) * NT): this k-step's four fragments have landed, the younger k-steps stay in flight
+            constexpr int VM = (RING - 2) * NT;
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (VM & 15) | ((VM >> 4) << 14));   // lgkmcnt / expcnt untouched
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             if (!((sk >> mt) & 1u)) {
@@ -177,19 +223,22 @@ __device__ __forceinline__ void conv_tap4(const uint8_t* bufX, const uint8_t* tr
     for (int mt = 0; mt < MT; mt++) ap[mt] = np[mt];
 }
 
-__global__ __launch_bounds__(THREADS, 1) void k_tower_sb4(const uint8_t* __restrict__ in88, int in_stride, int n,
+template <int NB>
+__global__ __launch_bounds__(THREADS, 1) void k_tower_sb(const uint8_t* __restrict__ in88, int in_stride, int n,
                                                           const uint16_t* __restrict__ stem_wp, const uint16_t* __restrict__ tower_wp,
                                                           const float* __restrict__ fold, int blocks, const float* __restrict__ hp,
                                                           float* __restrict__ pi_out, float* __restrict__ v_out,
                                                           unsigned long long* __restrict__ diag, const int* __restrict__ slot_map)
 {
+    using G = SB<NB>;
+    constexpr int ROWS = G::ROWS, MT = G::MT, ZR = G::ZR, RING = G::RING;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t* bufX = lds;
-    uint8_t* bufF = lds + FEAT_OFF;
-    uint8_t* in_l = lds + IN88_OFF;
-    uint8_t* rowof = lds + ROWOF_OFF;
-    uint8_t* taprow = lds + TAPROW_OFF;
-    uint16_t* rowcell = reinterpret_cast<uint16_t*>(lds + ROWCELL_OFF);
+    uint8_t* bufF = lds + G::FEAT_OFF;
+    uint8_t* in_l = lds + G::IN88_OFF;
+    uint8_t* rowof = lds + G::ROWOF_OFF;
+    uint8_t* taprow = lds + G::TAPROW_OFF;
+    uint16_t* rowcell = reinterpret_cast<uint16_t*>(lds + G::ROWCELL_OFF);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;        // MFMA fragment coordinates: board cell (column) c of a tile, k-group g
     const int board0 = blockIdx.x * NB;
@@ -223,7 +272,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb4(const uint8_t* __restr
     for (int i = tid; i < ZR; i += THREADS) rowcell[i] = 0xffffu;
     __syncthreads();
     for (int i = tid; i < ROWS; i += THREADS) {
-        const int b = i / 42, pos = i - b * 42, r = row_of4(b, pos);
+        const int b = i / 42, pos = i - b * 42, r = row_of<NB>(b, pos);
         rowof[i] = (uint8_t)r;
         rowcell[r] = (uint16_t)((pos / 6) | ((pos % 6) << 4) | (b << 8));
     }
@@ -251,7 +300,6 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb4(const uint8_t* __restr
     f32x4 acc[MT][NT];
     uint2 res[MT][NT];      // the block input of this wave's (cell, 4-channel) elements, packed bf16: the residual operand
     const uint32_t eoff = (uint32_t)(c * ROWB + (wave * 64 + g * 4) * 2);   // epilogue store address of tile 0 / column tile 0
-    const bool pad4 = c >= 8;                                                // lanes of tile 4 that hold pad rows
 
     // ---- stem: 3x3 conv 13 -> 256, two taps per 32-deep k-step (tap = 2*ks + (g >> 1), channels (g & 1)*8 ..), weights as
     //      the MFMA "A" operand: D[channel][cell], a lane ends up with 4 consecutive channels of one board cell
@@ -286,7 +334,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb4(const uint8_t* __restr
             for (int nt = 0; nt < NT; nt++) {
                 const uint2 o = bn_relu_pack<false>(acc[mt][nt], float4{sc, sc, sc, sc}, float4{sh, sh, sh, sh}, uint2{0, 0});
                 res[mt][nt] = o;
-                if (mt != 4 || !pad4) *reinterpret_cast<uint2*>(bufX + eoff + mt * 16 * ROWB + nt * 32) = o;
+                if (c < pad_from<NB>(mt)) *reinterpret_cast<uint2*>(bufX + eoff + mt * 16 * ROWB + nt * 32) = o;
             }
         }
     }
@@ -305,7 +353,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb4(const uint8_t* __restr
         uint32_t ap[MT];        // LDS byte address of this lane's fragment of tile mt at k-step 0 of the current tap
         s16x8 a[MT];            // ... and the fragment of the k-step about to run
         {
-            const uint32_t sk0 = skip_mask4(0);
+            const uint32_t sk0 = skip_mask<NB>(0);
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
                 ap[mt] = (uint32_t)tr_c[mt * 16] * ROWB + g16;
@@ -322,15 +370,15 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb4(const uint8_t* __restr
                 sh[nt] = *reinterpret_cast<const float4*>(fs + NF + nt * 16);
             }
         }
-        conv_tap4<0>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        conv_tap4<1>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        conv_tap4<2>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        conv_tap4<3>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        conv_tap4<4>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        conv_tap4<5>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        conv_tap4<6>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        conv_tap4<7>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        conv_tap4<8>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap<NB, 0>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap<NB, 1>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap<NB, 2>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap<NB, 3>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap<NB, 4>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap<NB, 5>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap<NB, 6>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap<NB, 7>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap<NB, 8>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
         __syncthreads();        // every wave has read the image for the last time
         if (L & 1) {    // second conv of a block: + shortcut (the block's input, kept packed in registers), and this
                         // output is the next block's input
@@ -340,7 +388,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb4(const uint8_t* __restr
                 for (int nt = 0; nt < NT; nt++) {
                     const uint2 o = bn_relu_pack<true>(acc[mt][nt], sc[nt], sh[nt], res[mt][nt]);
                     res[mt][nt] = o;
-                    if (mt != 4 || !pad4) *reinterpret_cast<uint2*>(bufX + eoff + mt * 16 * ROWB + nt * 32) = o;
+                    if (c < pad_from<NB>(mt)) *reinterpret_cast<uint2*>(bufX + eoff + mt * 16 * ROWB + nt * 32) = o;
                 }
         } else {
 #pragma unroll
@@ -348,7 +396,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb4(const uint8_t* __restr
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
                     const uint2 o = bn_relu_pack<false>(acc[mt][nt], sc[nt], sh[nt], uint2{0, 0});
-                    if (mt != 4 || !pad4) *reinterpret_cast<uint2*>(bufX + eoff + mt * 16 * ROWB + nt * 32) = o;
+                    if (c < pad_from<NB>(mt)) *reinterpret_cast<uint2*>(bufX + eoff + mt * 16 * ROWB + nt * 32) = o;
                 }
         }
         __syncthreads();        // the new image is complete
@@ -368,7 +416,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb4(const uint8_t* __restr
         const float* b1 = w1 + 42 * 256;    // [256]
         const float* w2 = b1 + 256;         // [256]
         const float* b2 = w2 + 256;         // [1]
-        float* feat = reinterpret_cast<float*>(lds + HEAD_OFF);   // [NB][128]: 84 policy features, then 42 value features
+        float* feat = reinterpret_cast<float*>(lds + G::HEAD_OFF);   // [NB][128]: 84 policy features, then 42 value features
         float* hid = feat + NB * 128;                             // [NB][256]
         float* logit = hid + NB * 256;                            // [NB][64]
         // 1x1 convs (256 -> 2 policy + 1 value channel per cell): the three weight columns are staged in LDS (the stem's
@@ -442,17 +490,26 @@ namespace azr {
 
 int tower_sb_init(azr_engine* h)
 {
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_sb4), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_sb<4>), hipFuncAttributeMaxDynamicSharedMemorySize, SB<4>::LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_sb<3>), hipFuncAttributeMaxDynamicSharedMemorySize, SB<3>::LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_sb<2>), hipFuncAttributeMaxDynamicSharedMemorySize, SB<2>::LDS_BYTES));
     return AZR_OK;
 }
 
-// `wgs` workgroups of 4 boards: boards [0, n) of the launch (the last workgroup may be partly filled)
+// `wgs` workgroups of nb (2, 3 or 4) boards: boards [0, n) of the launch (the last workgroup may be partly filled)
 int tower_sb_launch(azr_engine* h, int nb, int wgs, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st)
 {
-    if (nb != NB || wgs * NB < n) { h->err = "tower_sb_launch: bad tiling"; return AZR_E_INVALID_ARGUMENT; }
+    if (nb < 2 || nb > 4 || wgs < 1 || (long long)wgs * nb < n) { h->err = "tower_sb_launch: bad tiling"; return AZR_E_INVALID_ARGUMENT; }
     Bf16Net* x = bf16net(h);
-    hipLaunchKernelGGL(k_tower_sb4, dim3(wgs), dim3(THREADS), LDS_BYTES, st, d_in88, in_stride, n, x->stem_wp, x->tower_wp, net_fold(h),
-                       h->net.blocks, net_head_params(h), d_pi, d_v, x->diag, d_map);
+    if (nb == 4)
+        hipLaunchKernelGGL(k_tower_sb<4>, dim3(wgs), dim3(THREADS), SB<4>::LDS_BYTES, st, d_in88, in_stride, n, x->stem_wp, x->tower_wp, net_fold(h),
+                           h->net.blocks, net_head_params(h), d_pi, d_v, x->diag, d_map);
+    else if (nb == 3)
+        hipLaunchKernelGGL(k_tower_sb<3>, dim3(wgs), dim3(THREADS), SB<3>::LDS_BYTES, st, d_in88, in_stride, n, x->stem_wp, x->tower_wp, net_fold(h),
+                           h->net.blocks, net_head_params(h), d_pi, d_v, x->diag, d_map);
+    else
+        hipLaunchKernelGGL(k_tower_sb<2>, dim3(wgs), dim3(THREADS), SB<2>::LDS_BYTES, st, d_in88, in_stride, n, x->stem_wp, x->tower_wp, net_fold(h),
+                           h->net.blocks, net_head_params(h), d_pi, d_v, x->diag, d_map);
     HIPCHK(h, hipGetLastError());
     return AZR_OK;
 }

@@ -128,7 +128,7 @@ def test_bf16_tower_at_depth_matches_fp32_oracle(orc, n):
 
 @pytest.mark.parametrize("blocks", [20, 1, 2])
 def test_tile_shapes_agree_bit_for_bit(monkeypatch, blocks):
-    """the 4-boards-per-workgroup single-buffer kernel (azr_tower_sb.hip) and the 1..3-board kernels compute the same
+    """the 4- and 2-boards-per-workgroup single-buffer kernels (azr_tower_sb.hip) and the 1..3-board kernels compute the same
     bits: same k order, same fp32 epilogue, same rounding points (AZR_TOWER_SB is read once, at engine creation)"""
     P = pkg()
     n = 1024
@@ -136,19 +136,20 @@ def test_tile_shapes_agree_bit_for_bit(monkeypatch, blocks):
     x = g[np.linspace(0, len(g) - 1, n).astype(int)].copy()
     flat = T.make_net_flat(blocks, seed=3, perturb_bn=True)
     out = {}
-    for mode in ("0", "2"):
+    for mode in ("0", "1", "2", "3", "4"):
         monkeypatch.setenv("AZR_TOWER_SB", mode)
         eng = P.Engine(n, blocks=blocks, sims=1, dtype=P.NET_BF16, node_capacity=64)
         eng.set_weights(flat)
         out[mode] = eng.predict(x)
-        # a ragged batch (last workgroup partly filled) and a tiny one take the same values
-        p7, v7 = eng.predict(x[:1023])
-        assert (p7.view(np.uint32) == out[mode][0][:1023].view(np.uint32)).all() and (v7 == out[mode][1][:1023]).all()
-        p5, v5 = eng.predict(x[:5])
-        assert (p5.view(np.uint32) == out[mode][0][:5].view(np.uint32)).all() and (v5 == out[mode][1][:5]).all()
+        # ragged batches (last workgroup partly filled; in plan mode 700 / 400 boards take the 3- / 2-board tile) and a tiny
+        # one take the same values
+        for m in (1023, 700, 400, 5):
+            pm, vm = eng.predict(x[:m])
+            assert (pm.view(np.uint32) == out[mode][0][:m].view(np.uint32)).all() and (vm == out[mode][1][:m]).all(), (mode, m)
         eng.close()
-    assert (out["0"][0].view(np.uint32) == out["2"][0].view(np.uint32)).all()
-    assert (out["0"][1].view(np.uint32) == out["2"][1].view(np.uint32)).all()
+    for mode in ("1", "2", "3", "4"):   # the planned mix, then 4- / 2- / 3-board single-image tiles, against the two-image kernels
+        assert (out["0"][0].view(np.uint32) == out[mode][0].view(np.uint32)).all(), mode
+        assert (out["0"][1].view(np.uint32) == out[mode][1].view(np.uint32)).all(), mode
 
 
 def test_bf16_search_picks_the_fp32_search_moves(orc):
