@@ -68,7 +68,7 @@ EXPORTS = [
     "azr_nn_predict", "azr_nn_train", "azr_nn_train_dp", "azr_nn_train_batch", "azr_nn_train_grads", "azr_nn_train_reset", "azr_mcts_clear", "azr_mcts_trim", "azr_mcts_simulate", "azr_mcts_begin", "azr_mcts_leaves",
     "azr_mcts_apply", "azr_mcts_root_stats", "azr_mcts_policy", "azr_mcts_pick", "azr_selfplay_start", "azr_selfplay_start_games",
     "azr_selfplay_run", "azr_selfplay_counters", "azr_samples_drain", "azr_samples_device_view", "azr_samples_copy_device", "azr_profile_last_run",
-    "azr_device_synchronize", "azr_debug_tower_clock", "azr_debug_tower_trace", "azr_arena_start", "azr_arena_run", "azr_arena_results", "azr_arena_log",
+    "azr_device_synchronize", "azr_debug_tower_clock", "azr_debug_tower_trace", "azr_debug_tower_plan", "azr_arena_start", "azr_arena_run", "azr_arena_results", "azr_arena_log",
     "azr_arena_set_opponent_net", "azr_arena_collect_samples",
 ]
 
@@ -114,6 +114,7 @@ def load_library():
         L.azr_mcts_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.azr_mcts_root_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.azr_profile_last_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.azr_debug_tower_plan.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         for name in ("azr_engine_destroy", "azr_engine_games", "azr_mcts_clear", "azr_mcts_trim", "azr_mcts_simulate",
                      "azr_mcts_begin", "azr_device_synchronize"):
             getattr(L, name).argtypes = [C.c_void_p]
@@ -389,6 +390,12 @@ class Engine:
         n = C.c_size_t(0)
         self._chk(self.L.azr_samples_device_view(self.h, C.byref(ptr), C.byref(n)))
         return ptr.value, n.value
+
+    def tower_plan(self, n):
+        """(boards per workgroup, workgroups) of a bf16 net launch of n boards"""
+        nb, w = C.c_int(0), C.c_int(0)
+        self._chk(self.L.azr_debug_tower_plan(self.h, n, C.byref(nb), C.byref(w)))
+        return nb.value, w.value
 
     def profile_last_run(self):
         a, b, k = C.c_float(0), C.c_float(0), C.c_int(0)

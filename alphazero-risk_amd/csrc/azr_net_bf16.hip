@@ -626,6 +626,26 @@ int net_bf16_upload(azr_engine* h)
     return AZR_OK;
 }
 
+// Single-image tiles (azr_tower_sb.hip) for 2, 3 or 4 boards per workgroup: boards per workgroup for a launch of n boards,
+// or 0 = the two-image kernels (1..3 boards).  AZR_TOWER_SB: 0 = never, 1 = plan (default), 2 / 3 / 4 = force the 4- / 2- /
+// 3-board tile for every launch (tests, measurements).
+static int plan_sb(int sb_mode, int n)
+{
+    int snb = sb_mode == 2 ? 4 : sb_mode == 3 ? 2 : sb_mode == 4 ? 3 : 0;
+    if (sb_mode == 1 && n > 256) {
+        // measured launch time of one 256-workgroup round, ms (tools/tower_time.py): 2 / 3 / 4 boards per workgroup.
+        // One workgroup per CU is resident, so a launch of w workgroups takes ceil(w / 256) rounds.
+        static const float T[5] = {0.0f, 0.0f, 0.61f, 0.80f, 1.05f};
+        float best = 0.0f;
+        for (int c = 4; c >= 2; c--) {
+            const int w = (n + c - 1) / c;
+            const float ms = (float)((w + 255) / 256) * T[c];
+            if (snb == 0 || ms < best) { snb = c; best = ms; }
+        }
+    }
+    return n >= snb ? snb : 0;
+}
+
 int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st)
 {
     Bf16Net* x = bn(h);
@@ -645,26 +665,10 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
     if (nb == 0) { nb = 1; wgs = n_full = n; }          // fewer boards than CUs: one each
     else if (n_full == 0) n_full = W;                  // exact multiple: all workgroups carry nb
     else nb += 1;
-    // Single-image tiles (azr_tower_sb.hip) for 2, 3 or 4 boards per workgroup.  AZR_TOWER_SB: 0 = never (the two-image
-    // kernels only), 1 = plan (default), 2 / 3 / 4 = force the 4- / 2- / 3-board tile for every launch (tests, measurements).
-    {
-        int snb = x->sb_mode == 2 ? 4 : x->sb_mode == 3 ? 2 : x->sb_mode == 4 ? 3 : 0;
-        if (x->sb_mode == 1 && n > 256) {
-            // measured launch time of one 256-workgroup round, ms (tools/tower_time.py): 2 / 3 / 4 boards per workgroup.
-            // One workgroup per CU is resident, so a launch of w workgroups takes ceil(w / 256) rounds.
-            static const float T[5] = {0.0f, 0.0f, 0.61f, 0.80f, 1.05f};
-            float best = 0.0f;
-            for (int c = 4; c >= 2; c--) {
-                const int w = (n + c - 1) / c;
-                const float ms = (float)((w + 255) / 256) * T[c];
-                if (snb == 0 || ms < best) { snb = c; best = ms; }
-            }
-        }
-        if (snb && n >= snb) {
-            int rc = tower_sb_launch(h, snb, (n + snb - 1) / snb, d_in88, in_stride, n, d_pi, d_v, d_map, st);
-            if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
-            return rc;
-        }
+    if (const int snb = plan_sb(x->sb_mode, n)) {
+        int rc = tower_sb_launch(h, snb, (n + snb - 1) / snb, d_in88, in_stride, n, d_pi, d_v, d_map, st);
+        if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
+        return rc;
     }
     if (nb == 1) { if (NT == 2) LAUNCH_TOWER(1, 2); else LAUNCH_TOWER(1, 4); }
     else if (nb == 2) { if (NT == 2) LAUNCH_TOWER(2, 2); else LAUNCH_TOWER(2, 4); }
@@ -699,6 +703,17 @@ static int tower_diag_run(azr_engine* h, int n, int warm, std::vector<unsigned l
     HIPCHK(h, hipStreamSynchronize(h->stream));
     hipFree(d);
     return rc;
+}
+
+extern "C" int azr_debug_tower_plan(azr_engine* h, int n, int* boards_per_wg, int* wgs)
+{
+    if (!h || !h->net.bf16ctx || n < 1) return AZR_E_STATE;
+    const int snb = plan_sb(bn(h)->sb_mode, n);
+    if (snb) { *boards_per_wg = snb; *wgs = (n + snb - 1) / snb; return AZR_OK; }
+    const int rounds = (n + 767) / 768, W = 256 * rounds;   // the mixed 1..3-board launch of net_bf16_forward
+    *wgs = n < W ? n : W;
+    *boards_per_wg = (n + W - 1) / W;
+    return AZR_OK;
 }
 
 extern "C" int azr_debug_tower_clock(azr_engine* h, int n, int warm, double* ghz_out, double* tower_ms_out)

@@ -126,6 +126,11 @@ def run_config(ctx, games, sims, threads, steps, warmup, tail):
                      device=local, threads=threads)
     eng.init_random(20260002)
     eng.selfplay_start(shard.rank_base_seed(20260001, rank))
+    tower_kernel_name = "fp32 conv chain"
+    if a.dtype == "bf16":   # the tile plan of this configuration's launches (G x T leaf slots), from the library itself
+        nb, wgs = eng.tower_plan(games * threads)
+        tower_kernel_name = (f"k_tower_sb<{nb}>" if nb > 1 else "k_tower_bf16<1>") + \
+            f" x {wgs} workgroups of {nb} board(s) (one whole net forward of the G x T leaf slots: stem + 2B conv layers + both heads, one launch)"
 
     def barrier():
         torch.cuda.synchronize()
@@ -232,8 +237,7 @@ def run_config(ctx, games, sims, threads, steps, warmup, tail):
         "net_evals_per_s": tot["evaluations"] / dt, "mean_depth": levels / max(1, sims_total),
         "games_finished_in_timed_region": tot["games_finished"], "errors": tot["errors"],
         "nodes_dropped": tot["nodes_dropped"], "records_dropped": tot["records_dropped"],
-        "roofline": {"bound": "mfma", "kernel": "k_tower_bf16 (one whole net forward of the G x T leaf slots: stem + 2B conv layers + both heads, one launch)"
-                     if a.dtype == "bf16" else "fp32 conv chain", "achieved": achieved / 1e12,
+        "roofline": {"bound": "mfma", "kernel": tower_kernel_name if a.dtype == "bf16" else "fp32 conv chain", "achieved": achieved / 1e12,
                      "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
                      "flop_per_launch": leaves_per_launch * fps, "leaves_per_launch": leaves_per_launch,
                      "leaf_slots_per_launch": games * threads, "avg_launch_ms": prof["net_ms"],

@@ -228,6 +228,9 @@ int azr_device_synchronize(azr_engine* h);
  * workgroup-0 time after `warm` back-to-back launches on n leaf slots; per-workgroup time stamps of one launch */
 int azr_debug_tower_clock(azr_engine* h, int n, int warm, double* ghz_out, double* tower_ms_out);
 int azr_debug_tower_trace(azr_engine* h, int n, int warm, unsigned long long* out8, int cap_wgs, int* wgs_out);
+/* the tile plan of a bf16 net launch of n boards: boards per workgroup (the largest, in a mixed launch) and workgroups;
+ * 2..4 boards = k_tower_sb<NB> (one LDS image), 1 = k_tower_bf16<1> (AZR_TOWER_SB=0: k_tower_bf16<1..3>) */
+int azr_debug_tower_plan(azr_engine* h, int n, int* boards_per_wg, int* wgs);
 
 #ifdef __cplusplus
 }

@@ -13,10 +13,10 @@ pytestmark = pytest.mark.gpu
 FM = T.data_field_mask()
 
 
-@pytest.mark.parametrize("G,S,threads,passes", [(256, 100, 1, 450), (256, 100, 2, 300), (2048, 400, 2, 60)])
+@pytest.mark.parametrize("G,S,threads,passes", [(256, 100, 1, 450), (256, 100, 2, 300), (512, 100, 2, 200), (2048, 400, 2, 60)])
 def test_full_size_selfplay_invariants_and_determinism(orc, G, S, threads, passes):
-    """BASELINE configs[1] (G=256, S=100; at THREADS_PER_MCTS 1 and at the bench default 2) and configs[2] (G=2048,
-    S=400) shapes, B=20, bf16: two independent engines with the same seeds stay bit-identical (states, RNG streams,
+    """BASELINE configs[1] (G=256, S=100; at THREADS_PER_MCTS 1 and at the bench default 2), the metric's own point
+    (G=512, S=100: the bench headline) and configs[2] (G=2048, S=400) shapes, B=20, bf16: two independent engines with the same seeds stay bit-identical (states, RNG streams,
     counters); every exported state satisfies the reference's consistencyCheck identities; evaluation/simulation
     counters balance."""
     P = pkg()
