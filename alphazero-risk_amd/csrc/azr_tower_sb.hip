@@ -187,10 +187,6 @@ __device__ __forceinline__ void conv_tap(const uint8_t* bufX, const uint8_t* tr_
     for (int ks = 0; ks < KS_PER_TAP; ks++) {
         const int gk = TAP * KS_PER_TAP + ks;                       // k-step inside the layer (72 = 0 mod RING)
         const int cur = gk % RING, ref = (gk + RING - 1) % RING;    // ring slot in use / slot freed by the previous k-step
-        if (ks == KS_PER_TAP - 3) {   // the next tap's source rows, a little before they are needed
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) np[mt] = (uint32_t)tr_c[(TAP + 1) * ZR + mt * 16] * ROWB + g16;
-        }
         {   // vmcnt((RING - 2) * NT): this k-step's four fragments have landed, the younger k-steps stay in flight
             constexpr int VM = (RING - 2) * NT;
             __builtin_amdgcn_s_waitcnt(0x0F70 | (VM & 15) | ((VM >> 4) << 14));   // lgkmcnt / expcnt untouched
@@ -214,6 +210,10 @@ __device__ __forceinline__ void conv_tap(const uint8_t* bufX, const uint8_t* tr_
                 acc[mt][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[cur][3]), __builtin_bit_cast(bf16x8, a[mt]), acc[mt][3], 0, 0, 0);
                 if (ks < KS_PER_TAP - 1) a[mt] = lds16(bufX + ap[mt] + (ks + 1) * 64);
             }
+            // the next tap's source rows, dealt out like everything else: one table byte per tile slot two k-steps before
+            // the tap ends, its address arithmetic one k-step later (as a burst in front of a k-step they cost ~3 % of a layer)
+            if (ks == KS_PER_TAP - 3) { if (!((skn >> mt) & 1u)) np[mt] = (uint32_t)tr_c[(TAP + 1) * ZR + mt * 16]; }
+            if (ks == KS_PER_TAP - 2) { if (!((skn >> mt) & 1u)) np[mt] = np[mt] * ROWB + g16; }
             if (ks == KS_PER_TAP - 1) { if (!((skn >> mt) & 1u)) a[mt] = lds16(bufX + np[mt]); }
             __builtin_amdgcn_sched_barrier(0);
         }
