@@ -64,11 +64,16 @@ struct SB {
     static constexpr int ROWOF_OFF = IN88_OFF + NB * 96;        // u8 [ZR]: cell (board * 42 + pos) -> row
     static constexpr int TAPROW_OFF = ROWOF_OFF + ZR;           // u8 [10][ZR]: source row of (tap, row); tap 9 = all zero row
     static constexpr int ROWCELL_OFF = TAPROW_OFF + 10 * ZR;    // u16 [ZR]: row -> y | x << 4 | board << 8, 0xffff = pad row
-    static constexpr int LDS_BYTES = ROWCELL_OFF + 2 * ZR;
+    static constexpr int FOLD_OFF = (ROWCELL_OFF + 2 * ZR + 15) / 16 * 16;   // float [2][256]: the current layer's folded BN scale | shift
+    // the residual operand of the first RES_LDS row tiles lives here instead of in registers (NB = 4 only: 176 accumulators +
+    // 88 residual registers + ring + fragments do not fit the 512-register file without spills): uint2 [RES_LDS * NT][256 lanes]
+    static constexpr int RES_LDS = NB == 4 ? 6 : 0;
+    static constexpr int RES_OFF = FOLD_OFF + 2 * NF * 4;
+    static constexpr int LDS_BYTES = RES_OFF + RES_LDS * NT * THREADS * 8;
     static_assert(NB >= 2 && NB <= 4, "tile shapes");
     static_assert(72 % RING == 0 && RING <= MAX_RING, "ring depth");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static_assert(BUF % 16 == 0 && FEAT_OFF % 16 == 0 && HEAD_OFF % 16 == 0 && TAPROW_OFF % 4 == 0 && ROWCELL_OFF % 2 == 0, "alignment");
+    static_assert(BUF % 16 == 0 && FEAT_OFF % 16 == 0 && HEAD_OFF % 16 == 0 && FOLD_OFF % 16 == 0 && TAPROW_OFF % 4 == 0 && ROWCELL_OFF % 2 == 0, "alignment");
     static_assert(3 * NF * 4 <= (ZR + 1) * FROWB, "the heads stage 3 x 256 floats in the stem feature image");
 };
 
@@ -239,6 +244,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb(const uint8_t* __restri
     uint8_t* rowof = lds + G::ROWOF_OFF;
     uint8_t* taprow = lds + G::TAPROW_OFF;
     uint16_t* rowcell = reinterpret_cast<uint16_t*>(lds + G::ROWCELL_OFF);
+    float* foldl = reinterpret_cast<float*>(lds + G::FOLD_OFF);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;        // MFMA fragment coordinates: board cell (column) c of a tile, k-group g
     const int board0 = blockIdx.x * NB;
@@ -298,7 +304,11 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb(const uint8_t* __restri
     __syncthreads();
 
     f32x4 acc[MT][NT];
-    uint2 res[MT][NT];      // the block input of this wave's (cell, 4-channel) elements, packed bf16: the residual operand
+    // the block input of this wave's (cell, 4-channel) elements, packed bf16 = the residual operand: tiles RL.. in registers,
+    // tiles 0..RL-1 in LDS (one conflict-free 8-byte slot per lane, tile and column tile)
+    constexpr int RL = G::RES_LDS;
+    uint2 res[MT - RL][NT];
+    uint2* resl = reinterpret_cast<uint2*>(lds + G::RES_OFF) + tid;
     const uint32_t eoff = (uint32_t)(c * ROWB + (wave * 64 + g * 4) * 2);   // epilogue store address of tile 0 / column tile 0
 
     // ---- stem: 3x3 conv 13 -> 256, two taps per 32-deep k-step (tap = 2*ks + (g >> 1), channels (g & 1)*8 ..), weights as
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb(const uint8_t* __restri
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
                 const uint2 o = bn_relu_pack<false>(acc[mt][nt], float4{sc, sc, sc, sc}, float4{sh, sh, sh, sh}, uint2{0, 0});
-                res[mt][nt] = o;
+                if (mt < RL) resl[(mt * NT + nt) * THREADS] = o; else res[mt < RL ? 0 : mt - RL][nt] = o;
                 if (c < pad_from<NB>(mt)) *reinterpret_cast<uint2*>(bufX + eoff + mt * 16 * ROWB + nt * 32) = o;
             }
         }
@@ -350,6 +360,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb(const uint8_t* __restri
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) acc[mt][nt] = f32x4{0, 0, 0, 0};
+        const float2 fnext = *reinterpret_cast<const float2*>(fold + 14 + (size_t)L * 2 * NF + 2 * tid);   // (see the epilogue)
         uint32_t ap[MT];        // LDS byte address of this lane's fragment of tile mt at k-step 0 of the current tap
         s16x8 a[MT];            // ... and the fragment of the k-step about to run
         {
@@ -358,16 +369,6 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb(const uint8_t* __restri
             for (int mt = 0; mt < MT; mt++) {
                 ap[mt] = (uint32_t)tr_c[mt * 16] * ROWB + g16;
                 if (!((sk0 >> mt) & 1u)) a[mt] = lds16(bufX + ap[mt]);
-            }
-        }
-        // this layer's folded BN (4 consecutive channels per lane and column tile)
-        float4 sc[NT], sh[NT];
-        {
-            const float* fs = fold + 14 + (size_t)L * 2 * NF + wave * 64 + g * 4;
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) {
-                sc[nt] = *reinterpret_cast<const float4*>(fs + nt * 16);
-                sh[nt] = *reinterpret_cast<const float4*>(fs + NF + nt * 16);
             }
         }
         conv_tap<NB, 0>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
@@ -379,15 +380,25 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb(const uint8_t* __restri
         conv_tap<NB, 6>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
         conv_tap<NB, 7>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
         conv_tap<NB, 8>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        // this layer's folded BN scale / shift go through LDS: 2 registers per lane over the k-steps instead of 32 (which the
+        // register allocator parked in scratch), written before the barrier, read back 16 bytes at a time after it
+        *reinterpret_cast<float2*>(foldl + 2 * tid) = fnext;
         __syncthreads();        // every wave has read the image for the last time
+        float4 sc[NT], sh[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            sc[nt] = *reinterpret_cast<const float4*>(foldl + wave * 64 + g * 4 + nt * 16);
+            sh[nt] = *reinterpret_cast<const float4*>(foldl + NF + wave * 64 + g * 4 + nt * 16);
+        }
         if (L & 1) {    // second conv of a block: + shortcut (the block's input, kept packed in registers), and this
                         // output is the next block's input
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
-                    const uint2 o = bn_relu_pack<true>(acc[mt][nt], sc[nt], sh[nt], res[mt][nt]);
-                    res[mt][nt] = o;
+                    const uint2 x = mt < RL ? resl[(mt * NT + nt) * THREADS] : res[mt < RL ? 0 : mt - RL][nt];
+                    const uint2 o = bn_relu_pack<true>(acc[mt][nt], sc[nt], sh[nt], x);
+                    if (mt < RL) resl[(mt * NT + nt) * THREADS] = o; else res[mt < RL ? 0 : mt - RL][nt] = o;
                     if (c < pad_from<NB>(mt)) *reinterpret_cast<uint2*>(bufX + eoff + mt * 16 * ROWB + nt * 32) = o;
                 }
         } else {
