@@ -104,7 +104,7 @@ def test_alphazero_vs_script_config0_bit_exact(orc, az_first):
     eng.close()
 
 
-@pytest.mark.parametrize("threads,b_first,sb", [(1, False, None), (2, False, None), (2, True, None), (2, False, "2")])
+@pytest.mark.parametrize("threads,b_first,sb", [(1, False, None), (2, False, None), (2, True, None), (2, False, "2"), (2, False, "3"), (2, True, "4")])
 def test_two_net_arena_bit_exact_with_samples(orc, monkeypatch, threads, b_first, sb):
     """New-vs-old arena of the learn loop (GameGroup::playGames(trainAZPG, generateAZPG, ..., trainStorage),
     alphazero_trainer.cpp:143-152): two AlphaZero players with their own trees and DIFFERENT networks in every slot, each
@@ -112,7 +112,7 @@ def test_two_net_arena_bit_exact_with_samples(orc, monkeypatch, threads, b_first
     same game driver with the two DEVICE nets called back per evaluation."""
     P = pkg()
     G, per_slot, S, B, base = 6, 2, 12, 1, 5200
-    if sb:   # every net launch of 4 boards or more on the 4-boards-per-workgroup tile, through its leaf-slot map
+    if sb:   # every net launch on the single-image tiles ("2": 4 boards per workgroup, "3": 2, "4": 3), through the leaf-slot map
         monkeypatch.setenv("AZR_TOWER_SB", sb)
     a = P.Engine(G, blocks=B, sims=S, dtype=P.NET_BF16, threads=threads, max_game_rounds=40)
     b = P.Engine(G, blocks=B, sims=S, dtype=P.NET_BF16, threads=threads, max_game_rounds=40)
