@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "azr_internal.hpp"
+#include "azr_rowclass.hpp"
 
 using namespace azr;
 
@@ -530,6 +531,211 @@ __global__ __launch_bounds__(256) void t_conv_sb(Parts A, Parts Bp, float* __res
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// t_conv_rs: the same two conv GEMMs (forward, backward-data) with what the inference tower (azr_tower_sb.hip) taught:
+//   * a block owns 2 boards = 84 rows in BORDER-CLASS order (azr_rowclass.hpp, 6 MFMA row tiles): the 9 of 54 (tile, tap)
+//     pairs that lie wholly outside the board are not issued (17 % of the MFMAs and fragment reads);
+//   * 4 waves x 64 output channels (four 16-wide tiles): an activation fragment read from LDS feeds 4 MFMAs per pass,
+//     and MFMA(weights, activations) leaves 4 consecutive channels of one cell in a lane: 16-byte stores;
+//   * K order = channel chunk outermost (8 chunks of 32 input channels), tap innermost: only the current 32-channel slice
+//     of the 84 rows has to be in LDS (two buffers; the next slice is fetched during the 9 k-steps of the current one):
+//     ONE barrier per 9 k-steps; the 9 taps are unrolled with compile-time skip masks, the chunk loop is rolled;
+//   * weights straight from global memory in MFMA-fragment order (t_pack_w) through a ring of 3 k-steps, refill loads
+//     and fragment re-reads dealt out one per pass instead of as bursts.
+// AMODE 1: C[row] = sum_tap A[row + tap] W[tap]; AMODE 2 (backward-data): negated taps, i.e. loop index t reads the
+// geometric tap 8 - t, with the transposed kernel view.  `boards` = rows / 42 (the last block may hold one board).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+template <int NP> struct RsPass;
+template <> struct RsPass<3> { static constexpr int N = 6; static constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0}; };
+template <> struct RsPass<2> { static constexpr int N = 3; static constexpr int QA[3] = {1, 0, 0}, QB[3] = {0, 1, 0}; };
+
+// geometry of t_conv_rs (below)
+struct Rs {
+    static constexpr int NB = 2, ROWS = 84, MT = 6, ZR = 96, NT = 4, RING = 3;
+    static constexpr int CHB = 80;                       // bytes per row of a 32-channel slice (64 + 16 pad)
+    static constexpr int PB = (ZR + 1) * CHB;            // one part of one slice, incl. the shared zero row
+    static constexpr uint32_t KB = 16 * 64 * 16;         // bytes of one k-step of packed weights (16 column tiles x 64 lanes x 16 B)
+};
+
+// one k-step (one tap of one 32-channel slice) of t_conv_rs; everything that depends on the tap is a compile-time constant
+template <int AMODE, int NP, int TAP>
+__device__ __forceinline__ void rs_tap(const uint8_t* bufc, int kc, const __amdgpu_buffer_rsrc_t (&wsrc)[NP], uint32_t loff,
+                                       const uint32_t (&arow)[9][Rs::MT], u32x4 (&bq)[Rs::RING][NP][Rs::NT], f32x4 (&acc)[Rs::MT][Rs::NT],
+                                       s16x8 (&a)[Rs::MT][NP])
+{
+    constexpr int NB = Rs::NB, MT = Rs::MT, NT = Rs::NT, RING = Rs::RING, PB = Rs::PB, NPASS = RsPass<NP>::N;
+    constexpr uint32_t sk = skip_mask<NB>(AMODE == 2 ? 8 - TAP : TAP);
+    constexpr uint32_t skn = TAP < 8 ? skip_mask<NB>(AMODE == 2 ? 7 - TAP : TAP + 1) : 0xffffffffu;
+    constexpr int active = MT - __builtin_popcount(sk & ((1u << MT) - 1u));
+    constexpr int cur = TAP % RING, ref = (TAP + RING - 1) % RING;
+    // the k-step RING - 1 ahead in consumption order (chunk-major): tap + 2 of this chunk or tap - 7 of the next
+    constexpr int tap2 = (TAP + RING - 1) % 9;
+    const uint32_t koff = (uint32_t)(tap2 * 8 + kc + (TAP + RING - 1 >= 9 ? 1 : 0)) * Rs::KB;   // (past the layer: out of range -> 0)
+    constexpr int slots = active * NPASS;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        if (!((sk >> mt) & 1u)) {
+            const int j = __builtin_popcount(~sk & ((1u << mt) - 1u));
+#pragma unroll
+            for (int p = 0; p < NPASS; p++) {
+                const int qa = RsPass<NP>::QA[p], qb = RsPass<NP>::QB[p];
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[cur][qb][nt]),
+                                                                            __builtin_bit_cast(bf16x8, a[mt][qa]), acc[mt][nt], 0, 0, 0);
+                // one refill load of the ring slot the previous k-step freed, dealt out over the k-step
+                const int s2 = j * NPASS + p;
+#pragma unroll
+                for (int i = 0; i < NP * NT; i++)
+                    if (s2 == ((i + 1) * slots) / (NP * NT) - 1)
+                        bq[ref][i / NT][i % NT] = __builtin_amdgcn_raw_buffer_load_b128(wsrc[i / NT], loff + (i % NT) * 1024, (int)koff, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!((skn >> mt) & 1u)) {   // this tile's fragments for the next tap
+#pragma unroll
+                for (int q = 0; q < NP; q++) a[mt][q] = *reinterpret_cast<const s16x8*>(bufc + q * PB + arow[TAP < 8 ? TAP + 1 : 0][mt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)   // tiles idle in this tap that run in the next
+        if (((sk >> mt) & 1u) && !((skn >> mt) & 1u)) {
+#pragma unroll
+            for (int q = 0; q < NP; q++) a[mt][q] = *reinterpret_cast<const s16x8*>(bufc + q * PB + arow[TAP < 8 ? TAP + 1 : 0][mt]);
+        }
+}
+
+template <int AMODE, int NP>
+__global__ __launch_bounds__(256, 1) void t_conv_rs(Parts A, Parts Bp, float* __restrict__ C, int boards)
+{
+    constexpr int NB = Rs::NB, ROWS = Rs::ROWS, MT = Rs::MT, ZR = Rs::ZR, NT = Rs::NT, RING = Rs::RING, CHB = Rs::CHB, PB = Rs::PB;
+    constexpr int UN = (NP * ROWS * 4 + 255) / 256;   // 16-byte units of a slice per thread
+    constexpr uint32_t KB = Rs::KB;
+    __shared__ __attribute__((aligned(16))) uint8_t img[2 * NP * PB];
+    __shared__ uint8_t rowof[ROWS];
+    __shared__ uint8_t taprow[9 * ZR];
+    __shared__ uint16_t rowcell[ZR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int b0 = blockIdx.x * NB, m0 = b0 * NPOS;
+    const int nbv = boards - b0 < NB ? boards - b0 : NB;
+
+    // ---- weight ring: the first two k-steps (chunk 0, taps 0 and 1) fly while the tables are built
+    __amdgpu_buffer_rsrc_t wsrc[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) wsrc[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Bp.p[q]), (short)0, (int)(WPACK * 2), 0x00020000);
+    const uint32_t loff = (uint32_t)((wave * NT) * 64 + lane) * 16u;
+    u32x4 bq[RING][NP][NT];
+#pragma unroll
+    for (int s2 = 0; s2 < RING - 1; s2++)
+#pragma unroll
+        for (int q = 0; q < NP; q++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) bq[s2][q][nt] = __builtin_amdgcn_raw_buffer_load_b128(wsrc[q], loff + nt * 1024, (int)((s2 * 8) * KB), 0);
+
+    // ---- tables
+    for (int i = tid; i < ZR; i += 256) rowcell[i] = 0xffffu;
+    for (int i = tid; i < 2 * NP * (CHB / 4); i += 256) {   // the zero rows of both buffers
+        const int bp = i / (CHB / 4), w4 = i % (CHB / 4);
+        reinterpret_cast<uint32_t*>(img + bp * PB + ZR * CHB)[w4] = 0u;
+    }
+    __syncthreads();
+    for (int i = tid; i < ROWS; i += 256) {
+        const int b = i / NPOS, pos = i - b * NPOS, r = row_of<NB>(b, pos);
+        rowof[i] = (uint8_t)r;
+        rowcell[r] = (uint16_t)((pos / 6) | ((pos % 6) << 4) | (b << 8));
+    }
+    __syncthreads();
+    for (int i = tid; i < 9 * ZR; i += 256) {
+        const int t = i / ZR, r = i - t * ZR, ci = rowcell[r];
+        int src = ZR;
+        if (ci != 0xffff) {
+            const int y = (ci & 15) + t / 3 - 1, x = ((ci >> 4) & 15) + t % 3 - 1;
+            if ((unsigned)y < 7u && (unsigned)x < 6u) src = rowof[(ci >> 8) * NPOS + y * 6 + x];
+        }
+        taprow[i] = (uint8_t)src;
+    }
+    // this thread's units of a slice: (part, cell, 16-byte segment) -> global element offset (chunk 0) and LDS byte offset
+    size_t goff[UN];
+    uint32_t loffs[UN];
+    bool uok[UN];
+#pragma unroll
+    for (int i = 0; i < UN; i++) {
+        const int u = tid + 256 * i, q = u / (ROWS * 4), rem = u - q * (ROWS * 4), cell = rem >> 2, seg = rem & 3;
+        uok[i] = u < NP * ROWS * 4 && cell < nbv * NPOS;
+        goff[i] = (size_t)(m0 + cell) * NF + seg * 8;
+        loffs[i] = (uint32_t)((u < NP * ROWS * 4 ? q : 0) * PB + (u < NP * ROWS * 4 ? rowof[cell] : 0) * CHB + seg * 16);
+    }
+    auto fetch = [&](int kc, uint4 (&r)[UN]) {
+#pragma unroll
+        for (int i = 0; i < UN; i++) {
+            const int q = (tid + 256 * i) / (ROWS * 4);
+            r[i] = uok[i] ? *reinterpret_cast<const uint4*>(A.p[q < NP ? q : 0] + goff[i] + kc * 32) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto stash = [&](int buf, const uint4 (&r)[UN]) {
+#pragma unroll
+        for (int i = 0; i < UN; i++)
+            if (tid + 256 * i < NP * ROWS * 4) *reinterpret_cast<uint4*>(img + buf * NP * PB + loffs[i]) = r[i];
+    };
+    {
+        uint4 r0[UN];
+        fetch(0, r0);
+        stash(0, r0);
+    }
+    __syncthreads();
+    // per lane: byte offset of its fragment row for (loop tap, tile) inside a part of a slice
+    uint32_t arow[9][MT];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) arow[t][mt] = (uint32_t)taprow[(AMODE == 2 ? 8 - t : t) * ZR + mt * 16 + c] * CHB + g * 16;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s16x8 a[MT][NP];
+
+    for (int kc = 0; kc < 8; kc++) {
+        uint4 nx[UN];
+        if (kc + 1 < 8) fetch(kc + 1, nx);
+        const uint8_t* bufc = img + (kc & 1) * NP * PB;
+        {   // the fragments of tap 0 of this slice (the slice became visible with the barrier that ended the previous chunk)
+            constexpr uint32_t sk0 = skip_mask<NB>(AMODE == 2 ? 8 : 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+                if (!((sk0 >> mt) & 1u))
+#pragma unroll
+                    for (int q = 0; q < NP; q++) a[mt][q] = *reinterpret_cast<const s16x8*>(bufc + q * PB + arow[0][mt]);
+        }
+        rs_tap<AMODE, NP, 0>(bufc, kc, wsrc, loff, arow, bq, acc, a);
+        rs_tap<AMODE, NP, 1>(bufc, kc, wsrc, loff, arow, bq, acc, a);
+        rs_tap<AMODE, NP, 2>(bufc, kc, wsrc, loff, arow, bq, acc, a);
+        rs_tap<AMODE, NP, 3>(bufc, kc, wsrc, loff, arow, bq, acc, a);
+        rs_tap<AMODE, NP, 4>(bufc, kc, wsrc, loff, arow, bq, acc, a);
+        rs_tap<AMODE, NP, 5>(bufc, kc, wsrc, loff, arow, bq, acc, a);
+        rs_tap<AMODE, NP, 6>(bufc, kc, wsrc, loff, arow, bq, acc, a);
+        rs_tap<AMODE, NP, 7>(bufc, kc, wsrc, loff, arow, bq, acc, a);
+        rs_tap<AMODE, NP, 8>(bufc, kc, wsrc, loff, arow, bq, acc, a);
+        if (kc + 1 < 8) stash((kc + 1) & 1, nx);
+        __syncthreads();
+    }
+    // ---- C rows back in natural order: a lane holds 4 consecutive channels of one cell
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        const int ci = rowcell[mt * 16 + c];
+        if (ci == 0xffff || (ci >> 8) >= nbv) continue;
+        float* out = C + (size_t)(m0 + (ci >> 8) * NPOS + (ci & 15) * 6 + ((ci >> 4) & 15)) * NF + wave * 64 + g * 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+            *reinterpret_cast<float4*>(out + nt * 16) = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+    }
+}
+
 // out[i] = sum_z part[z][i]
 __global__ void t_sum_slices(const float* __restrict__ part, int nz, size_t n, float* __restrict__ out)
 {
@@ -735,8 +941,10 @@ __global__ __launch_bounds__(1024) void t_bn_finalize(const double* __restrict__
             bn[3 * NF + c] = bn[3 * NF + c] * BN_KEEP + (float)(var * count / (count - 1.0)) * (1.0f - BN_KEEP);
         }
     } else {
-        for (int g = 0; g < NG; g++) {
+        {   // grid of NG blocks: one board row each (the sums of a row keep their order)
+            const int g = blockIdx.x;
             double s = 0.0, ss = 0.0;
+#pragma unroll 8
             for (int b = q; b < R; b += 4) {
                 s += part[((size_t)b * 2 * NG + g) * NF + c];
                 ss += part[((size_t)b * 2 * NG + NG + g) * NF + c];
@@ -858,8 +1066,10 @@ __global__ __launch_bounds__(1024) void t_bn_bwd_finalize(const double* __restri
             sums[NF + c] = (float)sx;
         }
     } else {
-        for (int g = 0; g < NG; g++) {
+        {   // grid of NG blocks: one board row each
+            const int g = blockIdx.x;
             double s = 0.0, sx = 0.0;
+#pragma unroll 8
             for (int b = q; b < R; b += 4) {
                 s += part[((size_t)b * 2 * NG + g) * NF + c];
                 sx += part[((size_t)b * 2 * NG + NG + g) * NF + c];
@@ -1070,6 +1280,7 @@ __global__ void t_head_reduce(const float* __restrict__ hpart, int BS, float* __
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= HP_FLOATS) return;
     float s = 0.0f;
+#pragma unroll 16   // (loads in flight together; the additions keep their order)
     for (int b = 0; b < BS; b++) s += hpart[(size_t)b * HP_FLOATS + i];
     int o;
     if (i < HP_PD_B) o = H_PD_W + i;
@@ -1108,9 +1319,9 @@ __global__ __launch_bounds__(1024) void t_head_bn_bwd(const float* __restrict__ 
         const float mu = hstat[ch], is = hstat[3 + ch];
         const double s = hsum[ch], sx = hsum[3 + ch];
         const int C = ch < 2 ? 2 : 1, k = ch < 2 ? ch : 0, base = ch < 2 ? H_PI_BN : H_V_BN;
-        if (threadIdx.x == 0) { ghead[base + k] = (float)sx * gscale; ghead[base + C + k] = (float)s * gscale; }
+        if (threadIdx.x == 0 && blockIdx.x == 0) { ghead[base + k] = (float)sx * gscale; ghead[base + C + k] = (float)s * gscale; }
         const float gamma = hp[base + k], fs = (float)s / n, fsx = (float)sx / n;
-        for (int r = threadIdx.x; r < M; r += 1024) {
+        for (int r = blockIdx.x * 1024 + threadIdx.x; r < M; r += gridDim.x * 1024) {
             const float dz = dpv[(size_t)r * 4 + ch];
             const float xh = (pv0[(size_t)r * 4 + ch] - mu) * is;
             dpv[(size_t)r * 4 + ch] = gamma * is * (dz - fs - xh * fsx);
@@ -1139,6 +1350,7 @@ __global__ __launch_bounds__(256) void t_head_conv_bwd_finalize(const float* __r
 {
     const int c = threadIdx.x;
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll 8
     for (int b = 0; b < R; b++) {
         g0 += part[((size_t)b * 3 + 0) * NF + c];
         g1 += part[((size_t)b * 3 + 1) * NF + c];
@@ -1187,6 +1399,9 @@ __global__ void t_adam(float* __restrict__ w, const float* __restrict__ g, float
 // =====================================================================================================================
 // conv GEMM arithmetic: split bf16 (default; 6-pass forward, 3-pass backward) or the fp32 MFMA (AZR_TRAIN_GEMM=f32)
 bool g_gemm_bf16x3 = true;
+// which split-bf16 conv kernels: t_conv_rs (default) or the older t_conv_sb (AZR_TRAIN_GEMM=sb: kept as the second
+// implementation the tests compare against)
+bool g_conv_rs = true;
 
 struct TrainCtx {
     int BS = 0, blocks = 0, M = 0, L = 0, R = 0, nz = 0, kchunk = 0;
@@ -1258,6 +1473,7 @@ int ctx_ensure(azr_engine* h, int BS)
     if (c && c->BS == BS) return AZR_OK;
     // tuning switch, read when a training context is (re)built — never in the step path
     g_gemm_bf16x3 = !(getenv("AZR_TRAIN_GEMM") && strcmp(getenv("AZR_TRAIN_GEMM"), "f32") == 0);
+    g_conv_rs = !(getenv("AZR_TRAIN_GEMM") && strcmp(getenv("AZR_TRAIN_GEMM"), "sb") == 0);
     // a different batch size rebuilds the activation slabs but keeps the optimiser state
     std::vector<float> keep_m, keep_v;
     long keep_step = 0;
@@ -1409,7 +1625,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     gemm<false, false, 64>(st, c->col0, KS, c->wpad, NF, Yl(0), NF, M, NF, KS);
     hipLaunchKernelGGL((t_bn_stats<true>), dim3(R), dim3(1024), 0, st, Yl(0), M, c->part);
     if (dp) TRY(reduce_parts(2 * NG));
-    hipLaunchKernelGGL((t_bn_finalize<true>), dim3(1), dim3(1024), 0, st, dp ? c->red : c->part, dp ? 1 : R, (double)BSg * 6 * NF, c->mean, c->istd,
+    hipLaunchKernelGGL((t_bn_finalize<true>), dim3(NG), dim3(1024), 0, st, dp ? c->red : c->part, dp ? 1 : R, (double)BSg * 6 * NF, c->mean, c->istd,
                        w + OFF_STEM_BN);
     uint16_t* const nil16 = nullptr;
     // (each layer's normalise kernel also writes the three bf16 parts of its output: the next conv's A operand)
@@ -1419,7 +1635,8 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         float* bn = Wl(l) + (size_t)9 * NF * NF;
         const float* S = (l % 2 == 0) ? Al(l - 2) : nullptr;  // second conv of a block adds the block input
         if (sb) {  // conv = implicit im2col x W, 6-pass split bf16 (fp32-exact products)
-            hipLaunchKernelGGL((t_conv_sb<1, 3, 1>), dim3(2, (M + 63) / 64), dim3(256), 0, st, Parts{{c->ap[0], c->ap[1], c->ap[2]}}, Wpf(l), Yl(l), M);
+            if (g_conv_rs) hipLaunchKernelGGL((t_conv_rs<1, 3>), dim3((BS + 1) / 2), dim3(256), 0, st, Parts{{c->ap[0], c->ap[1], c->ap[2]}}, Wpf(l), Yl(l), BS);
+            else hipLaunchKernelGGL((t_conv_sb<1, 3, 1>), dim3(2, (M + 63) / 64), dim3(256), 0, st, Parts{{c->ap[0], c->ap[1], c->ap[2]}}, Wpf(l), Yl(l), M);
         } else gemm<false, false, 64, 1, 0>(st, Al(l - 1), KC, Wl(l), NF, Yl(l), NF, M, NF, KC);
         hipLaunchKernelGGL((t_bn_stats<false>), dim3(R), dim3(1024), 0, st, Yl(l), M, c->part);
         if (dp) TRY(reduce_parts(2));
@@ -1443,7 +1660,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     hipLaunchKernelGGL(t_head_reduce, grid1(HP_FLOATS, 256), dim3(256), 0, st, c->hpart, BS, gh);
     hipLaunchKernelGGL(t_head_bn_bwd_sums, dim3(1), dim3(1024), 0, st, c->pv0, c->hstat, M, (const float*)c->dpv, c->hsum);
     if (dp) TRY(dp_allreduce(h, c, c->hsum, 6, 1));
-    hipLaunchKernelGGL(t_head_bn_bwd, dim3(1), dim3(1024), 0, st, c->pv0, hp, c->hstat, M, (const double*)c->hsum, (float)Mg, gscale, c->dpv, gh);
+    hipLaunchKernelGGL(t_head_bn_bwd, dim3((M + 1023) / 1024), dim3(1024), 0, st, c->pv0, hp, c->hstat, M, (const double*)c->hsum, (float)Mg, gscale, c->dpv, gh);
     hipLaunchKernelGGL(t_head_conv_bwd, dim3(R), dim3(256), 0, st, H, c->dpv, hp, M, c->G, c->cpart);
     hipLaunchKernelGGL(t_head_conv_bwd_finalize, dim3(1), dim3(256), 0, st, c->cpart, R, gh);
     const float invM = 1.0f / (float)Mg;
@@ -1468,14 +1685,15 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, c->nz, wn, Gl(l));
         // d(input) = transposed conv of dY with W: the same implicit GEMM with negated taps and W read as [tap][co] x [ci]
         float* dIn = second ? c->DT : c->G;
-        if (sb) hipLaunchKernelGGL((t_conv_sb<2, 2, 1>), dim3(2, (M + 63) / 64), dim3(256), 0, st, Parts{{c->dyp[0], c->dyp[1], nullptr}}, Wpb(l), dIn, M);
+        if (sb && g_conv_rs) hipLaunchKernelGGL((t_conv_rs<2, 2>), dim3((BS + 1) / 2), dim3(256), 0, st, Parts{{c->dyp[0], c->dyp[1], nullptr}}, Wpb(l), dIn, BS);
+        else if (sb) hipLaunchKernelGGL((t_conv_sb<2, 2, 1>), dim3(2, (M + 63) / 64), dim3(256), 0, st, Parts{{c->dyp[0], c->dyp[1], nullptr}}, Wpb(l), dIn, M);
         else gemm<false, true, 64, 2, 3>(st, c->dY, KC, Wl(l), NF, dIn, NF, M, NF, KC);
         if (!second) hipLaunchKernelGGL(t_add, dim3(g4), dim3(256), 0, st, dIn, c->DS, act / 4);  // + shortcut gradient
     }
     {   // stem: parameters only
         hipLaunchKernelGGL((t_bn_bwd_stats<true>), dim3(R), dim3(1024), 0, st, c->G, Al(0), Yl(0), c->mean, c->istd, M, c->part);
         if (dp) TRY(reduce_parts(2 * NG));
-        hipLaunchKernelGGL((t_bn_bwd_finalize<true>), dim3(1), dim3(1024), 0, st, dp ? c->red : c->part, dp ? 1 : R, g + OFF_STEM_BN, c->sums, gscale);
+        hipLaunchKernelGGL((t_bn_bwd_finalize<true>), dim3(NG), dim3(1024), 0, st, dp ? c->red : c->part, dp ? 1 : R, g + OFF_STEM_BN, c->sums, gscale);
         hipLaunchKernelGGL((t_bn_bwd_apply<true>), dim3(g4), dim3(256), 0, st, c->G, Al(0), Yl(0), c->mean, c->istd, w + OFF_STEM_BN, c->sums,
                            1.0f / ((float)BSg * 6 * NF), c->dY, (float*)nullptr, M, nil16, nil16);
         gemm<true, false>(st, c->col0, KS, c->dY, NF, c->wpart, NF, KS, NF, M, c->nz, c->kchunk, (size_t)KS * NF);

@@ -37,13 +37,30 @@ def records(n, seed=0):
     return rec
 
 
-def torch_step(blocks, flat, rec):
-    """loss, gradients (AZRW layout, without the L2 term) and post-step BN moving statistics from the PyTorch graph"""
+def torch_step(blocks, flat, rec, margin=None):
+    """loss, gradients (AZRW layout, without the L2 term) and post-step BN moving statistics from the PyTorch graph.
+    margin (a list): receives the smallest non-zero |ReLU input| of the float64 forward — an fp32 forward whose rounding
+    lands on the other side of such an input flips one mask, a discrete change of the gradients (measured: flips at
+    2.5e-7 .. 6.4e-7, none at 1.1e-6, with either conv kernel)"""
     net = train.AzrNet(blocks, flat).double()
     net.train()
     in88, pi, z = train.unpack_records(rec)
     x = torch.from_numpy(train.planes_from_in88(in88)).double()
-    lp, lv, _ = net.losses(x, torch.from_numpy(pi).double(), torch.from_numpy(z).double())
+    relu0 = train.F.relu
+
+    def relu(t, *a, **k):
+        if margin is not None:
+            v = t.detach().abs()
+            v = v[v > 0]
+            if v.numel():
+                margin.append(float(v.min()))
+        return relu0(t, *a, **k)
+
+    train.F.relu = relu
+    try:
+        lp, lv, _ = net.losses(x, torch.from_numpy(pi).double(), torch.from_numpy(z).double())
+    finally:
+        train.F.relu = relu0
     (lp + lv).backward()
     g = np.zeros(net.count, np.float64)
     for name, off, shape in net.lay:
@@ -83,23 +100,32 @@ def tf_adam(w, g, m, v, t, k):
     return np.where(tr, w2, w), np.where(tr, m2, m), np.where(tr, v2, v)
 
 
-@pytest.mark.parametrize("blocks,bs,gemm", [(1, 16, "split"), (2, 64, "split"), (2, 64, "f32"), (1, 10, "split")])
+@pytest.mark.parametrize("blocks,bs,gemm", [(1, 16, "split"), (2, 64, "split"), (2, 64, "sb"), (2, 64, "f32"), (1, 10, "split")])
 def test_step_matches_torch_graph(blocks, bs, gemm, monkeypatch):
-    """gemm = "split": the split-bf16 conv GEMMs (default); "f32": the fp32-MFMA GEMMs (AZR_TRAIN_GEMM=f32); batch 10
-    (42 * 10 rows, not a multiple of the 32-deep k-tile) takes the fp32 kernels by itself"""
-    if gemm == "f32":
-        monkeypatch.setenv("AZR_TRAIN_GEMM", "f32")
+    """gemm = "split": the split-bf16 conv GEMMs (default: t_conv_rs, 2 boards per block in border-class row order);
+    "sb": the same arithmetic in the older 64-row tiles (AZR_TRAIN_GEMM=sb); "f32": the fp32-MFMA GEMMs
+    (AZR_TRAIN_GEMM=f32); batch 10 (42 * 10 rows, not a multiple of the 32-deep k-tile) takes the fp32 kernels by itself"""
+    if gemm in ("f32", "sb"):
+        monkeypatch.setenv("AZR_TRAIN_GEMM", gemm)
     else:
         monkeypatch.delenv("AZR_TRAIN_GEMM", raising=False)
     P = pkg()
     flat = T.make_net_flat(blocks, seed=11, perturb_bn=True)
-    rec = records(bs, seed=blocks)
+    # the first record seed whose float64 forward keeps every ReLU input at least 1e-6 away from zero: the gradient
+    # tolerance below is then not at the mercy of one mask flipped by fp32 rounding (see torch_step)
+    for seed in range(blocks + 1, blocks + 33):
+        rec = records(bs, seed=seed)
+        margin = []
+        rlp, rlv, rg, rflat = torch_step(blocks, flat, rec, margin)
+        if min(margin) >= 1e-6:
+            break
+    else:
+        pytest.fail("no record seed with a ReLU margin of 1e-6")
     eng = P.Engine(8, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64)
     eng.set_weights(flat)
     lp, lv = eng.train_batch(rec)
     g = eng.train_grads()
     w1 = eng.get_weights()
-    rlp, rlv, rg, rflat = torch_step(blocks, flat, rec)
     # losses: fp32 vs float64 reference
     assert abs(lp - rlp) <= 2e-5 * max(1, abs(rlp)) and abs(lv - rlv) <= 2e-5, (lp, rlp, lv, rlv)
     # gradients per tensor: max error relative to the tensor's largest gradient
