@@ -736,6 +736,131 @@ __global__ __launch_bounds__(256, 1) void t_conv_rs(Parts A, Parts Bp, float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// t_wgrad_rs: the weight gradient  dW[tap][ci][co] = sum over rows of A[row + tap][ci] * dY[row][co]  (split bf16, 3 passes).
+// The reduction runs over ROWS, the slow index of both operands ([row][channel] in memory): the MFMA wants 8 consecutive
+// rows of one channel per lane.  gfx950's transposed LDS read (ds_read_b64_tr_b16) delivers exactly that from row-major
+// tiles, and because every lane supplies the ADDRESS of one row of a 4-row block, the tap shift and the board-edge mask
+// cost nothing: an out-of-board source row is simply the address of a zero row (no im2col, no register transposes, no masks).
+//   block = one slice of whole boards (the split-K unit) x one 16-channel ci tile; 4 waves x 64 output channels;
+//   per wave 9 taps x 4 co tiles = 36 accumulator tiles: a dY fragment feeds 9 taps, an A fragment 4 co tiles;
+//   per k-step (32 rows) the block stages 32 rows x 256 co of dY and 46 rows (7 halo rows each side) x 16 ci of A, both
+//   parts, double-buffered through registers: one barrier per k-step of 108 MFMAs per wave.
+// Blocks of one slice are 16 apart in blockIdx (same XCD: the slice's dY is fetched into one L2).
+// ---------------------------------------------------------------------------------------------------------------------
+struct Wg {
+    static constexpr int KR = 32, HALO = 7, AR = KR + 2 * HALO;
+    // Tile rows are placed for conflict-free transposed reads: a 32-lane half reads 4 rows r..r+3 and the 4 rows 8 further,
+    // 32 bytes (8 banks) each; with a row pitch of 8 banks (mod 64) and 32 more banks in front of every further group of 8
+    // rows, the eight rows cover the 64 banks once — for any tap shift of the A rows too.
+    static constexpr int AST = 32;                 // bytes per row of the A tile (16 ci)
+    static constexpr int APB = (AR + 1) * AST + (AR / 8) * 128;   // one part: rows and gaps, incl. the zero row (row AR)
+    static constexpr int GST = 544;                // bytes per row of the dY tile (256 co + 32 B pad: 136 banks = 8 mod 64)
+    static constexpr int GPB = KR * GST + (KR / 8) * 128;
+    __host__ __device__ static constexpr int arow(int r) { return r * AST + (r >> 3) * 128; }
+    __host__ __device__ static constexpr int grow(int r) { return r * GST + (r >> 3) * 128; }
+    static constexpr int BUF = 2 * APB + 2 * GPB;  // A part 0 | A part 1 | dY part 0 | dY part 1
+    static constexpr int LDS_BYTES = 2 * BUF;
+};
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ s16x8 lds_tr8(const uint8_t* p_lo, const uint8_t* p_hi)
+{
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p_lo));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p_hi));
+    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(256, 1) void t_wgrad_rs(Parts A, Parts G, float* __restrict__ out, int M, int NS, int rows_per_slice)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t wg_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    const int slice = blockIdx.x % NS, cit = blockIdx.x / NS;
+    const int rbeg = slice * rows_per_slice, rend = min(M, rbeg + rows_per_slice);
+    const int nks = (rend - rbeg + Wg::KR - 1) / Wg::KR;
+
+    // zero rows of the A parts (both buffers)
+    for (int i = tid; i < 4 * (Wg::AST / 4); i += 256)
+        reinterpret_cast<uint32_t*>(wg_lds + (i / (Wg::AST / 4) >> 1) * Wg::BUF + (i / (Wg::AST / 4) & 1) * Wg::APB + Wg::arow(Wg::AR))[i % (Wg::AST / 4)] = 0u;
+
+    // staging units of this thread: 8 of the dY tile (part, row, 16-byte segment), at most 1 of the A tile
+    uint4 sg[8], sa;
+    const int a_part = tid / 92, a_rem = tid - a_part * 92, a_row = a_rem >> 1, a_seg = a_rem & 1;
+    const bool a_unit = tid < 184;
+    const uint16_t* a_src = (a_part ? A.p[1] : A.p[0]) + cit * 16 + a_seg * 8;   // (no run-time indexing of the kernel arguments)
+    auto fetch = [&](int ks) {
+        const int r0 = rbeg + ks * Wg::KR;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int idx = tid + 256 * i, part = idx >> 10, row = (idx >> 5) & 31, seg = idx & 31;
+            sg[i] = r0 + row < rend ? *reinterpret_cast<const uint4*>((i < 4 ? G.p[0] : G.p[1]) + (size_t)(r0 + row) * NF + seg * 8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        const int gr = r0 - Wg::HALO + a_row;
+        sa = (a_unit && gr >= 0 && gr < M) ? *reinterpret_cast<const uint4*>(a_src + (size_t)gr * NF) : make_uint4(0u, 0u, 0u, 0u);
+    };
+    auto stash = [&](int buf) {
+        uint8_t* b = wg_lds + buf * Wg::BUF;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int idx = tid + 256 * i, part = idx >> 10, row = (idx >> 5) & 31, seg = idx & 31;
+            *reinterpret_cast<uint4*>(b + 2 * Wg::APB + part * Wg::GPB + Wg::grow(row) + seg * 16) = sg[i];
+        }
+        if (a_unit) *reinterpret_cast<uint4*>(b + a_part * Wg::APB + Wg::arow(a_row) + a_seg * 16) = sa;
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the two tile rows this lane addresses in a transposed read: k1 = 8g + q and k1 + 4; their board cells
+    const int k1 = 8 * g + q;
+    int pos1 = k1 % NPOS, pos2 = (k1 + 4) % NPOS;      // (slices start on a board boundary)
+    const uint32_t a_zero = (uint32_t)(Wg::arow(Wg::AR) + p * 8);
+    const uint32_t g_lo = (uint32_t)(2 * Wg::APB + Wg::grow(k1) + (wave * 64 + p * 4) * 2);
+    const uint32_t g_hi = (uint32_t)(2 * Wg::APB + Wg::grow(k1 + 4) + (wave * 64 + p * 4) * 2);
+
+    for (int ks = 0; ks < nks; ks++) {
+        if (ks + 1 < nks) fetch(ks + 1);
+        const uint8_t* b = wg_lds + (ks & 1) * Wg::BUF;
+        const int y1 = pos1 / 6, x1 = pos1 - 6 * y1, y2 = pos2 / 6, x2 = pos2 - 6 * y2;
+        s16x8 gf[2][4];   // dY fragments [part][co tile]
+#pragma unroll
+        for (int part = 0; part < 2; part++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) gf[part][c] = lds_tr8(b + g_lo + part * Wg::GPB + c * 32, b + g_hi + part * Wg::GPB + c * 32);
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1, sh = Wg::HALO + dy * 6 + dx;   // source tile row = k + sh
+            const bool v1 = (unsigned)(y1 + dy) < 7u && (unsigned)(x1 + dx) < 6u, v2 = (unsigned)(y2 + dy) < 7u && (unsigned)(x2 + dx) < 6u;
+            const uint32_t o1 = v1 ? (uint32_t)(Wg::arow(k1 + sh) + p * 8) : a_zero, o2 = v2 ? (uint32_t)(Wg::arow(k1 + 4 + sh) + p * 8) : a_zero;
+            const s16x8 ah = lds_tr8(b + o1, b + o2), am = lds_tr8(b + Wg::APB + o1, b + Wg::APB + o2);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, am), __builtin_bit_cast(bf16x8, gf[0][c]), acc[t][c], 0, 0, 0);
+                acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, gf[1][c]), acc[t][c], 0, 0, 0);
+                acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, gf[0][c]), acc[t][c], 0, 0, 0);
+            }
+        }
+        pos1 += Wg::KR; if (pos1 >= NPOS) pos1 -= NPOS;
+        pos2 += Wg::KR; if (pos2 >= NPOS) pos2 -= NPOS;
+        if (ks + 1 < nks) stash((ks + 1) & 1);
+        __syncthreads();
+    }
+    float* o = out + (size_t)slice * KC * NF;
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                o[(size_t)(t * NF + cit * 16 + 4 * g + e) * NF + wave * 64 + c * 16 + i16] = acc[t][c][e];
+}
+
 // out[i] = sum_z part[z][i]
 __global__ void t_sum_slices(const float* __restrict__ part, int nz, size_t n, float* __restrict__ out)
 {
@@ -1405,6 +1530,7 @@ bool g_conv_rs = true;
 
 struct TrainCtx {
     int BS = 0, blocks = 0, M = 0, L = 0, R = 0, nz = 0, kchunk = 0;
+    int wg_slices = 0, wg_rows = 0;          // t_wgrad_rs: row slices (split-K units of whole boards) and rows per slice
     size_t count = 0;
     long step = 0;
     float *g = nullptr, *m = nullptr, *v = nullptr;
@@ -1474,6 +1600,7 @@ int ctx_ensure(azr_engine* h, int BS)
     // tuning switch, read when a training context is (re)built — never in the step path
     g_gemm_bf16x3 = !(getenv("AZR_TRAIN_GEMM") && strcmp(getenv("AZR_TRAIN_GEMM"), "f32") == 0);
     g_conv_rs = !(getenv("AZR_TRAIN_GEMM") && strcmp(getenv("AZR_TRAIN_GEMM"), "sb") == 0);
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(t_wgrad_rs), hipFuncAttributeMaxDynamicSharedMemorySize, Wg::LDS_BYTES));
     // a different batch size rebuilds the activation slabs but keeps the optimiser state
     std::vector<float> keep_m, keep_v;
     long keep_step = 0;
@@ -1505,7 +1632,13 @@ int ctx_ensure(azr_engine* h, int BS)
     TRY(dalloc(h, c, &c->mean, (size_t)c->L * NF)); TRY(dalloc(h, c, &c->istd, (size_t)c->L * NF));
     TRY(dalloc(h, c, &c->sums, (size_t)2 * NF));
     TRY(dalloc(h, c, &c->part, (size_t)c->R * 2 * NG * NF));
-    TRY(dalloc(h, c, &c->wpart, (size_t)c->nz * KC * NF));
+    // t_wgrad_rs: slices of 16 j boards (16 boards = 672 rows = 21 k-steps), about 256 blocks = 16 ci tiles x slices
+    {
+        const int bps = 16 * std::max(1, BS / 256);
+        c->wg_slices = (BS + bps - 1) / bps;
+        c->wg_rows = bps * NPOS;
+    }
+    TRY(dalloc(h, c, &c->wpart, (size_t)std::max(c->nz, c->wg_slices) * KC * NF));
     for (int q = 0; q < 3; q++) { TRY(dalloc(h, c, &c->ap[q], act)); TRY(dalloc(h, c, &c->wpf[q], (size_t)2 * B * KC * NF)); }
     for (int q = 0; q < 2; q++) TRY(dalloc(h, c, &c->wpb[q], (size_t)2 * B * KC * NF));
     for (int q = 0; q < 2; q++) TRY(dalloc(h, c, &c->dyp[q], act));
@@ -1679,10 +1812,14 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         // dW = col(input)^T x dY  (implicit im2col, split-K over the M rows)
         if (sb) {
             hipLaunchKernelGGL((t_split<2>), dim3(g4), dim3(256), 0, st, Al(l - 1), act / 4, c->ap[0], c->ap[1], (uint16_t*)nullptr);
-            gemm_sb<true, false, 128, 1, 0, 2>(st, Parts{{c->ap[0], c->ap[1], nullptr}}, KC, Parts{{c->dyp[0], c->dyp[1], nullptr}}, NF, c->wpart,
-                                               NF, KC, NF, M, c->nz, c->kchunk, wn);
+            if (g_conv_rs)
+                hipLaunchKernelGGL(t_wgrad_rs, dim3(16 * c->wg_slices), dim3(256), Wg::LDS_BYTES, st, Parts{{c->ap[0], c->ap[1], nullptr}},
+                                   Parts{{c->dyp[0], c->dyp[1], nullptr}}, c->wpart, M, c->wg_slices, c->wg_rows);
+            else
+                gemm_sb<true, false, 128, 1, 0, 2>(st, Parts{{c->ap[0], c->ap[1], nullptr}}, KC, Parts{{c->dyp[0], c->dyp[1], nullptr}}, NF, c->wpart,
+                                                   NF, KC, NF, M, c->nz, c->kchunk, wn);
         } else gemm<true, false, 128, 1, 0>(st, Al(l - 1), KC, c->dY, NF, c->wpart, NF, KC, NF, M, c->nz, c->kchunk, wn);
-        hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, c->nz, wn, Gl(l));
+        hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, (sb && g_conv_rs) ? c->wg_slices : c->nz, wn, Gl(l));
         // d(input) = transposed conv of dY with W: the same implicit GEMM with negated taps and W read as [tap][co] x [ci]
         float* dIn = second ? c->DT : c->G;
         if (sb && g_conv_rs) hipLaunchKernelGGL((t_conv_rs<2, 2>), dim3((BS + 1) / 2), dim3(256), 0, st, Parts{{c->dyp[0], c->dyp[1], nullptr}}, Wpb(l), dIn, BS);
