@@ -14,7 +14,8 @@
 // value is the exact sum of three bf16 parts; the forward multiplies all parts that matter (6 MFMA passes, fp32-exact
 // products, so ReLU masks and batch statistics are those of an fp32 forward), the two gradient GEMMs use two parts (3
 // passes, 1e-5 relative) — with t_gemm on the fp32 MFMA (v_mfma_f32_32x32x2_f32) kept for the stem (K = 144), odd
-// batch sizes and AZR_TRAIN_GEMM=f32.
+// batch sizes and AZR_TRAIN_GEMM=f32.  Kernels of the split-bf16 path: t_conv_rs (forward, backward-data) and t_wgrad_rs
+// (weight gradient) by default; t_conv_sb / t_gemm_sb (the round-1 tiles) under AZR_TRAIN_GEMM=sb.
 // Every conv output (pre-BN) and every post-activation is kept for the backward pass: 2 x 22 MB per layer at batch 512,
 // 1.8 GB for the 41 conv layers of B = 20 — sized for 288 GB of HBM, nothing is recomputed.
 // Reductions (BN statistics, bias / BN / head gradients, split-K) are two-stage and atomic-free: a step is
