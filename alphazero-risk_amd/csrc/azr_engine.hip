@@ -974,6 +974,7 @@ extern "C" int azr_engine_destroy(azr_engine* h)
     train_free(h);
     net_free(h);
     for (hipEvent_t e : h->ev) hipEventDestroy(e);
+    if (h->arena_ev) hipEventDestroy(h->arena_ev);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return AZR_OK;
@@ -1471,6 +1472,7 @@ extern "C" int azr_arena_run(azr_engine* h, int passes, int* finished_out)
     const bool needs_net = h->d.kind0 == AZR_PLAYER_ALPHAZERO || h->d.kind1 == AZR_PLAYER_ALPHAZERO;
     if (h->d.nodes2) {  // two networks: every pass evaluates each net on the leaves of its own player only
         const int GT = h->d.G * h->d.T;
+        if (!h->arena_ev) HIPCHK(h, hipEventCreateWithFlags(&h->arena_ev, hipEventDisableTiming));
         for (int p = 0; p < passes; p++) {
             HIPCHK(h, hipMemsetAsync(h->d.leaf_count, 0, 2 * sizeof(int), h->stream));
             LAUNCH(h, k_arena_step, h->d);
@@ -1478,10 +1480,18 @@ extern "C" int azr_arena_run(azr_engine* h, int passes, int* finished_out)
             D2H(h, cnt, h->d.leaf_count, sizeof cnt);
             SYNC(h);
             if (cnt[0] == 0 && cnt[1] == 0) break;  // every slot is idle: the quota is exhausted
+            // The two launches are independent (own weights, disjoint leaf slots) and small — an arena of 100 games is
+            // 1 board per workgroup on fewer than half of the CUs each — so they run side by side: this net on this
+            // handle's stream, the opponent's on the opponent's; the next tree step waits for both.  (The tree step that
+            // wrote the leaves has completed: the count read-back above synchronised the stream.)
             int rc = net_forward_ex(h, h->d.leaf_in, LEAF_STRIDE, cnt[0], h->d.net_pi, h->d.net_v, h->d.leaf_list, h->stream);
             if (rc) return rc;
-            rc = net_forward_ex(h->opponent, h->d.leaf_in, LEAF_STRIDE, cnt[1], h->d.net_pi, h->d.net_v, h->d.leaf_list + GT, h->stream);
-            if (rc) { h->err = h->opponent->err; return rc; }
+            if (cnt[1] > 0) {
+                rc = net_forward_ex(h->opponent, h->d.leaf_in, LEAF_STRIDE, cnt[1], h->d.net_pi, h->d.net_v, h->d.leaf_list + GT, h->opponent->stream);
+                if (rc) { h->err = h->opponent->err; return rc; }
+                HIPCHK(h, hipEventRecord(h->arena_ev, h->opponent->stream));
+                HIPCHK(h, hipStreamWaitEvent(h->stream, h->arena_ev, 0));
+            }
         }
     } else
     for (int p = 0; p < passes; p++) {

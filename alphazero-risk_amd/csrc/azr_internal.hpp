@@ -112,6 +112,7 @@ struct azr_engine {
     bool weights_set;
     void* tree2[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // nodes2, touch2, nhash2, table2, freel2, tctl2
     azr_engine* opponent = nullptr;  // handle whose network plays AZR_PLAYER_ALPHAZERO_B (azr_arena_set_opponent_net)
+    hipEvent_t arena_ev = nullptr;   // two-net arena: the opponent's net launch (on ITS stream) done -> this stream may go on
     bool sp_tail = false;         // quota self-play: no game is left to start, slots go idle -> compacted net batches
     void* train = nullptr;        // azr_train.hip: optimiser state + activation slabs, created by the first azr_nn_train*
 };
