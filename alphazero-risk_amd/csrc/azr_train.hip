@@ -1640,7 +1640,9 @@ int ctx_ensure(azr_engine* h, int BS)
         c->wg_rows = bps * NPOS;
     }
     TRY(dalloc(h, c, &c->wpart, (size_t)std::max(c->nz, c->wg_slices) * KC * NF));
-    for (int q = 0; q < 3; q++) { TRY(dalloc(h, c, &c->ap[q], act)); TRY(dalloc(h, c, &c->wpf[q], (size_t)2 * B * KC * NF)); }
+    // bf16 parts of the post-activations: the two leading parts are kept PER LAYER (the weight-gradient GEMM of the backward
+    // pass wants exactly them: no second split), the third one only until the next forward conv has read it
+    for (int q = 0; q < 3; q++) { TRY(dalloc(h, c, &c->ap[q], q < 2 ? act * c->L : act)); TRY(dalloc(h, c, &c->wpf[q], (size_t)2 * B * KC * NF)); }
     for (int q = 0; q < 2; q++) TRY(dalloc(h, c, &c->wpb[q], (size_t)2 * B * KC * NF));
     for (int q = 0; q < 2; q++) TRY(dalloc(h, c, &c->dyp[q], act));
     TRY(dalloc(h, c, &c->pv0, M * 4)); TRY(dalloc(h, c, &c->dpv, M * 4)); TRY(dalloc(h, c, &c->hstat, (size_t)8));
@@ -1763,21 +1765,22 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
                        w + OFF_STEM_BN);
     uint16_t* const nil16 = nullptr;
     // (each layer's normalise kernel also writes the three bf16 parts of its output: the next conv's A operand)
+    auto Ap = [&](int l) { return Parts{{c->ap[0] + act * l, c->ap[1] + act * l, c->ap[2]}}; };   // parts of the post-activation of layer l
     hipLaunchKernelGGL((t_bn_apply<true>), dim3(g4), dim3(256), 0, st, Yl(0), c->mean, c->istd, w + OFF_STEM_BN, (const float*)nullptr, Al(0), M,
                        sb ? c->ap[0] : nil16, c->ap[1], c->ap[2]);
     for (int l = 1; l < c->L; l++) {
         float* bn = Wl(l) + (size_t)9 * NF * NF;
         const float* S = (l % 2 == 0) ? Al(l - 2) : nullptr;  // second conv of a block adds the block input
         if (sb) {  // conv = implicit im2col x W, 6-pass split bf16 (fp32-exact products)
-            if (g_conv_rs) hipLaunchKernelGGL((t_conv_rs<1, 3>), dim3((BS + 1) / 2), dim3(256), 0, st, Parts{{c->ap[0], c->ap[1], c->ap[2]}}, Wpf(l), Yl(l), BS);
-            else hipLaunchKernelGGL((t_conv_sb<1, 3, 1>), dim3(2, (M + 63) / 64), dim3(256), 0, st, Parts{{c->ap[0], c->ap[1], c->ap[2]}}, Wpf(l), Yl(l), M);
+            if (g_conv_rs) hipLaunchKernelGGL((t_conv_rs<1, 3>), dim3((BS + 1) / 2), dim3(256), 0, st, Ap(l - 1), Wpf(l), Yl(l), BS);
+            else hipLaunchKernelGGL((t_conv_sb<1, 3, 1>), dim3(2, (M + 63) / 64), dim3(256), 0, st, Ap(l - 1), Wpf(l), Yl(l), M);
         } else gemm<false, false, 64, 1, 0>(st, Al(l - 1), KC, Wl(l), NF, Yl(l), NF, M, NF, KC);
         hipLaunchKernelGGL((t_bn_stats<false>), dim3(R), dim3(1024), 0, st, Yl(l), M, c->part);
         if (dp) TRY(reduce_parts(2));
         hipLaunchKernelGGL((t_bn_finalize<false>), dim3(8), dim3(1024), 0, st, dp ? c->red : c->part, dp ? 1 : R, (double)Mg, c->mean + l * NF,
                            c->istd + l * NF, bn);
         hipLaunchKernelGGL((t_bn_apply<false>), dim3(g4), dim3(256), 0, st, Yl(l), c->mean + l * NF, c->istd + l * NF, bn, S, Al(l), M,
-                           (sb && l + 1 < c->L) ? c->ap[0] : nil16, c->ap[1], c->ap[2]);
+                           (sb && l + 1 < c->L) ? const_cast<uint16_t*>(Ap(l).p[0]) : nil16, const_cast<uint16_t*>(Ap(l).p[1]), c->ap[2]);
     }
     const float* H = Al(c->L - 1);
     hipLaunchKernelGGL(t_head_conv, grid1((size_t)M, 4), dim3(256), 0, st, H, hp, c->pv0, M);
@@ -1812,12 +1815,11 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
                            invM, c->dY, second ? c->DS : (float*)nullptr, M, sb ? c->dyp[0] : nil16, c->dyp[1]);
         // dW = col(input)^T x dY  (implicit im2col, split-K over the M rows)
         if (sb) {
-            hipLaunchKernelGGL((t_split<2>), dim3(g4), dim3(256), 0, st, Al(l - 1), act / 4, c->ap[0], c->ap[1], (uint16_t*)nullptr);
             if (g_conv_rs)
-                hipLaunchKernelGGL(t_wgrad_rs, dim3(16 * c->wg_slices), dim3(256), Wg::LDS_BYTES, st, Parts{{c->ap[0], c->ap[1], nullptr}},
+                hipLaunchKernelGGL(t_wgrad_rs, dim3(16 * c->wg_slices), dim3(256), Wg::LDS_BYTES, st, Parts{{Ap(l - 1).p[0], Ap(l - 1).p[1], nullptr}},
                                    Parts{{c->dyp[0], c->dyp[1], nullptr}}, c->wpart, M, c->wg_slices, c->wg_rows);
             else
-                gemm_sb<true, false, 128, 1, 0, 2>(st, Parts{{c->ap[0], c->ap[1], nullptr}}, KC, Parts{{c->dyp[0], c->dyp[1], nullptr}}, NF, c->wpart,
+                gemm_sb<true, false, 128, 1, 0, 2>(st, Parts{{Ap(l - 1).p[0], Ap(l - 1).p[1], nullptr}}, KC, Parts{{c->dyp[0], c->dyp[1], nullptr}}, NF, c->wpart,
                                                    NF, KC, NF, M, c->nz, c->kchunk, wn);
         } else gemm<true, false, 128, 1, 0>(st, Al(l - 1), KC, c->dY, NF, c->wpart, NF, KC, NF, M, c->nz, c->kchunk, wn);
         hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, (sb && g_conv_rs) ? c->wg_slices : c->nz, wn, Gl(l));
