@@ -189,7 +189,12 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
         # ---- trainGroup->train (alphazero_gpu_cluster.cpp:221-231)
         t0 = time.time()
         hist = []
-        dp = dist is not None and bool(getattr(a, "dp", 1)) and a.bs % world == 0 and a.bs // world >= 2
+        # --dp -1 (default): data-parallel only when every rank still gets a full 512-record slice.  At the reference's
+        # BATCH_SIZE 512 a rank's share is 512 / world records: the conv kernels of the step are one round of blocks on the
+        # GPU either way (a block's serial work sets the time, not the number of blocks), so the step gets no shorter, and
+        # it gains 2B + 4 latency-bound all-reduces of batch statistics plus one of 95 MB: rank 0 trains, as the reference does.
+        dp_flag = getattr(a, "dp", -1)
+        dp = dist is not None and a.bs % world == 0 and a.bs // world >= 2 and (dp_flag == 1 or (dp_flag < 0 and a.bs // world >= 512))
         if dp:
             # data-parallel optimiser step: every rank takes 1/world of each minibatch (same shuffle stream everywhere);
             # batch statistics, losses and the gradient vector are all-reduced (RCCL over xGMI), every rank takes the
@@ -273,9 +278,9 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--include-compare-samples", type=int, default=1)   # INCLUDE_COMPARE_GAMES_TRAIN_SAMPLES
-    ap.add_argument("--dp", type=int, default=1,
-                    help="multi-rank runs: 1 = data-parallel optimiser step over all ranks (default), 0 = rank 0 trains and broadcasts "
-                         "(the reference's AlphaZeroNNGroup::train)")
+    ap.add_argument("--dp", type=int, default=-1,
+                    help="multi-rank runs: 1 = data-parallel optimiser step over all ranks, 0 = rank 0 trains and broadcasts "
+                         "(the reference's AlphaZeroNNGroup::train), -1 (default) = data-parallel when --bs / world >= 512")
     a = ap.parse_args()
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1:

@@ -101,9 +101,11 @@ def test_host_stepped_arena_through_the_player_seam():
 
 
 @pytest.mark.gpu
-def test_two_rank_learn_iteration(tmp_path):
+@pytest.mark.parametrize("dp", ["1", "-1"])
+def test_two_rank_learn_iteration(tmp_path, dp):
     """the N > 1 learn path (BASELINE configs[4]) rehearsed with 2 ranks on this box's one GPU over gloo: sharded
-    self-play, all_gather of the records, training on rank 0, weight broadcast, sharded arena + benchmark with reduced
+    self-play, all_gather of the records, training (--dp 1: data-parallel optimiser step on both ranks; --dp -1, the
+    default: at 32 records per rank rank 0 trains and broadcasts the weights), sharded arena + benchmark with reduced
     GameResults; rank 0 writes the reference's files"""
     import socket
     import subprocess
@@ -112,7 +114,7 @@ def test_two_rank_learn_iteration(tmp_path):
     env = dict(os.environ, AZR_LEARN_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "alphazero-risk_amd", "learn.py"), "--ti", "1", "--tg", "8", "--mcts", "6",
-           "--gpu-games", "8", "--blocks", "1", "-e", "2", "--bs", "64", "--cg", "8", "--ct", "0"]
+           "--gpu-games", "8", "--blocks", "1", "-e", "2", "--bs", "64", "--cg", "8", "--ct", "0", "--dp", dp]
     r = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-2000:]
     assert "Model improved" in r.stdout and "Loss Policy / Value" in r.stdout
