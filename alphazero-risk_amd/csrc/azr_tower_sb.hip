@@ -1,25 +1,26 @@
-// azr_tower_sb.hip — k_tower_sb4: the whole policy/value net (python/src/build_graph.py:63-90) for FOUR boards per workgroup
-// with ONE LDS activation buffer (gfx950).
+// azr_tower_sb.hip — k_tower_sb<NB>: the whole policy/value net (python/src/build_graph.py:63-90) for NB = 2, 3 or 4 boards per
+// workgroup with ONE LDS activation image (gfx950).
 //
 // Why a second tower kernel.  k_tower_bf16 (azr_net_bf16.hip) keeps two ping-pong activation images in LDS, which caps a
-// workgroup at 3 boards (M = 128 GEMM rows) — and every workgroup streams the whole 47 MB of packed weights once per
-// launch from its XCD's L2.  At 1..2 boards per CU that stream (16 KB per 32-deep k-step per CU) runs at the practical
-// L2 -> CU rate (~65 GB/s per CU) and the matrix pipes wait for it.  The only way to need fewer weight bytes per board
-// is more boards per CU.  Here a workgroup owns 4 boards (168 cells, 11 MFMA row tiles) in a SINGLE LDS image:
+// workgroup at 3 boards (M = 128 GEMM rows), and its 8 waves x 32 channels read every activation fragment for 2 MFMAs only.
+// Here a workgroup owns up to 4 boards (168 cells, 11 MFMA row tiles) in a SINGLE LDS image:
 //   * a layer's whole output lives in accumulator registers until the layer's last k-step (it always did); the image is
 //     overwritten in place between two barriers (all waves done reading | epilogue stores | all stores visible);
 //   * the residual input of a block — the values this wave itself stored two layers earlier — stays packed (bf16) in
-//     registers instead of in a second image: 88 registers per lane;
+//     registers instead of in a second image (at 4 boards 6 of the 11 row tiles keep theirs in the LDS the single image
+//     leaves free: 176 accumulators + 88 residual registers + ring + fragments overflow the 512-register file);
 //   * 4 waves (one per SIMD, up to 512 registers each) split the 256 output channels, 64 (four 16-wide tiles) each, so an
 //     activation fragment read from LDS feeds 4 MFMAs: LDS fragment traffic per MFMA is half that of the 8-wave tiles;
 //   * per k-step a wave issues, tile by tile, [4 MFMAs | 1 ds_read_b128 of that tile's NEXT k-step fragment]; the 4 buffer
-//     loads that refill the weight-ring slot freed by the previous k-step are dealt out over the k-step, one per MFMA gap
-//     (ring of 4 slots, 3 k-steps ahead, never drained; the packed stream of all layers is contiguous, exactly as for
-//     k_tower_bf16 — both kernels read the same packed weights);
+//     loads that refill the weight-ring slot freed by the previous k-step, and the next tap's row-table lookups, are dealt
+//     out over the k-step, one per MFMA gap (ring of 4 slots, 3 k-steps ahead, never drained; the packed stream of all
+//     layers is contiguous, exactly as for k_tower_bf16 — both kernels read the same packed weights);
 //   * the layer loop is rolled (conv1 and conv2 of a block share the code; only the epilogue looks at the parity) and a
 //     layer's 72 k-steps are fully unrolled with compile-time skip masks: ~40 KB of straight-line code, inside the
-//     64 KB instruction cache.
-// Row order (border classes, see row_of4): 15 of the 99 (tile, tap) pairs are entirely out of board and are skipped.
+//     64 KB instruction cache;
+//   * a layer's folded BN scale / shift reach the epilogue through LDS (2 registers per lane over the k-steps, not 32).
+// Row order (border classes with the corners in the column classes, azr_rowclass.hpp): 18 of 99 / 12 of 72 / 9 of 54
+// (tile, tap) pairs are entirely out of board and are skipped.
 // Arithmetic is the k_tower_bf16 arithmetic — same k order, same fp32 epilogue, same RNE points — so results are
 // bit-identical across tile shapes (tests/test_gpu_net.py checks it).
 #include <stdlib.h>
