@@ -765,11 +765,72 @@ struct Wg {
 };
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-__device__ __forceinline__ s16x8 lds_tr8(const uint8_t* p_lo, const uint8_t* p_hi)
+// transposed read of one MFMA operand fragment: two 4-row blocks (rows k..k+3 of the lane's group, then k+4..k+7); the
+// arguments are absolute LDS addresses (no base to add), IMM a compile-time byte offset that lands in the instruction
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+template <int IMM>
+__device__ __forceinline__ s16x8 lds_tr8(uint32_t a_lo, uint32_t a_hi)
 {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p_lo));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p_hi));
-    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>((uintptr_t)a_lo) + IMM / 8);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>((uintptr_t)a_hi) + IMM / 8);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// one k-step (32 rows) of t_wgrad_rs.  With one wave per SIMD nothing hides a latency: the A fragments of tap t + 1 are
+// requested BEFORE the 12 MFMAs of tap t are issued (two fragment slots, pinned with scheduling barriers — left alone, the
+// compiler reuses one slot and waits for every read in front of its MFMAs), and everything else is kept to the reads
+// themselves, one v_cndmask per A read (valid source row or the zero row: the row addresses are loop-invariant registers,
+// part offsets are instruction immediates) and eight edge tests per k-step whose combinations per tap are scalar.
+// The addresses passed in point into this k-step's buffer (the caller moves them to the other buffer after every k-step:
+// one loop body — two copies of the k-step in one loop made the compiler shuffle all 144 accumulators at the back-edge).
+template <int T>
+__device__ __forceinline__ void wg_afrag(int y1, int x1, int y2, int x2, const uint32_t (&aoff)[9][2], uint32_t a_zero, s16x8& ah, s16x8& am)
+{
+    constexpr int dy = T / 3 - 1, dx = T % 3 - 1;
+    const bool v1 = (dy < 0 ? y1 > 0 : dy > 0 ? y1 < 6 : true) && (dx < 0 ? x1 > 0 : dx > 0 ? x1 < 5 : true);
+    const bool v2 = (dy < 0 ? y2 > 0 : dy > 0 ? y2 < 6 : true) && (dx < 0 ? x2 > 0 : dx > 0 ? x2 < 5 : true);
+    const uint32_t o1 = v1 ? aoff[T][0] : a_zero, o2 = v2 ? aoff[T][1] : a_zero;
+    ah = lds_tr8<0>(o1, o2);
+    am = lds_tr8<Wg::APB>(o1, o2);
+}
+template <int T>
+__device__ __forceinline__ void wg_tap(int y1, int x1, int y2, int x2, const uint32_t (&aoff)[9][2], uint32_t a_zero, const s16x8 (&gf)[2][4],
+                                       s16x8 (&ah)[2], s16x8 (&am)[2], f32x4 (&acc)[9][4])
+{
+    if constexpr (T + 1 < 9) wg_afrag<T + 1>(y1, x1, y2, x2, aoff, a_zero, ah[(T + 1) & 1], am[(T + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        acc[T][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, am[T & 1]), __builtin_bit_cast(bf16x8, gf[0][c]), acc[T][c], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        acc[T][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[T & 1]), __builtin_bit_cast(bf16x8, gf[1][c]), acc[T][c], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        acc[T][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[T & 1]), __builtin_bit_cast(bf16x8, gf[0][c]), acc[T][c], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void wg_kstep(int& pos1, int& pos2, const uint32_t (&aoff)[9][2], uint32_t a_zero, uint32_t g_lo, uint32_t g_hi,
+                                         f32x4 (&acc)[9][4])
+{
+    const int y1 = pos1 / 6, x1 = pos1 - 6 * y1, y2 = pos2 / 6, x2 = pos2 - 6 * y2;
+    s16x8 gf[2][4];   // dY fragments [part][co tile]
+    s16x8 ah[2], am[2];
+    gf[0][0] = lds_tr8<0>(g_lo, g_hi); gf[0][1] = lds_tr8<32>(g_lo, g_hi); gf[0][2] = lds_tr8<64>(g_lo, g_hi); gf[0][3] = lds_tr8<96>(g_lo, g_hi);
+    wg_afrag<0>(y1, x1, y2, x2, aoff, a_zero, ah[0], am[0]);
+    gf[1][0] = lds_tr8<Wg::GPB>(g_lo, g_hi); gf[1][1] = lds_tr8<Wg::GPB + 32>(g_lo, g_hi);
+    gf[1][2] = lds_tr8<Wg::GPB + 64>(g_lo, g_hi); gf[1][3] = lds_tr8<Wg::GPB + 96>(g_lo, g_hi);
+    wg_tap<0>(y1, x1, y2, x2, aoff, a_zero, gf, ah, am, acc);
+    wg_tap<1>(y1, x1, y2, x2, aoff, a_zero, gf, ah, am, acc);
+    wg_tap<2>(y1, x1, y2, x2, aoff, a_zero, gf, ah, am, acc);
+    wg_tap<3>(y1, x1, y2, x2, aoff, a_zero, gf, ah, am, acc);
+    wg_tap<4>(y1, x1, y2, x2, aoff, a_zero, gf, ah, am, acc);
+    wg_tap<5>(y1, x1, y2, x2, aoff, a_zero, gf, ah, am, acc);
+    wg_tap<6>(y1, x1, y2, x2, aoff, a_zero, gf, ah, am, acc);
+    wg_tap<7>(y1, x1, y2, x2, aoff, a_zero, gf, ah, am, acc);
+    wg_tap<8>(y1, x1, y2, x2, aoff, a_zero, gf, ah, am, acc);
+    pos1 += Wg::KR; if (pos1 >= NPOS) pos1 -= NPOS;
+    pos2 += Wg::KR; if (pos2 >= NPOS) pos2 -= NPOS;
 }
 
 __global__ __launch_bounds__(256, 1) void t_wgrad_rs(Parts A, Parts G, float* __restrict__ out, int M, int NS, int rows_per_slice)
@@ -779,35 +840,49 @@ __global__ __launch_bounds__(256, 1) void t_wgrad_rs(Parts A, Parts G, float* __
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
     const int slice = blockIdx.x % NS, cit = blockIdx.x / NS;
     const int rbeg = slice * rows_per_slice, rend = min(M, rbeg + rows_per_slice);
-    const int nks = (rend - rbeg + Wg::KR - 1) / Wg::KR;
+    const int nks = (rend - rbeg) / Wg::KR;    // whole k-steps: slices are multiples of 16 boards = 21 k-steps
 
     // zero rows of the A parts (both buffers)
     for (int i = tid; i < 4 * (Wg::AST / 4); i += 256)
         reinterpret_cast<uint32_t*>(wg_lds + (i / (Wg::AST / 4) >> 1) * Wg::BUF + (i / (Wg::AST / 4) & 1) * Wg::APB + Wg::arow(Wg::AR))[i % (Wg::AST / 4)] = 0u;
 
-    // staging units of this thread: 8 of the dY tile (part, row, 16-byte segment), at most 1 of the A tile
-    uint4 sg[8], sa;
-    const int a_part = tid / 92, a_rem = tid - a_part * 92, a_row = a_rem >> 1, a_seg = a_rem & 1;
-    const bool a_unit = tid < 184;
-    const uint16_t* a_src = (a_part ? A.p[1] : A.p[0]) + cit * 16 + a_seg * 8;   // (no run-time indexing of the kernel arguments)
-    auto fetch = [&](int ks) {
-        const int r0 = rbeg + ks * Wg::KR;
+    // staging units of this thread: 8 of the dY tile (the same (row, segment) of part 0 and part 1, four times: always inside
+    // the slice) and at most 1 of the A tile (part 0: waves 0, 1; part 1: waves 2, 3; halo rows before row 0 or after row
+    // M - 1 are out of range of the buffer resource and read as 0).  Buffer loads: the k-step advances a scalar offset.
+    const __amdgpu_buffer_rsrc_t gsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(G.p[0]), (short)0, M * NF * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(G.p[1]), (short)0, M * NF * 2, 0x00020000);
+    const int a_part = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int a_rem = tid & 127, a_row = a_rem >> 1, a_seg = a_rem & 1;
+    const bool a_unit = a_rem < 2 * Wg::AR;
+    const __amdgpu_buffer_rsrc_t asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a_part ? A.p[1] : A.p[0]), (short)0, M * NF * 2, 0x00020000);
+    uint32_t goffs[4], gl[4];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int idx = tid + 256 * i, part = idx >> 10, row = (idx >> 5) & 31, seg = idx & 31;
-            sg[i] = r0 + row < rend ? *reinterpret_cast<const uint4*>((i < 4 ? G.p[0] : G.p[1]) + (size_t)(r0 + row) * NF + seg * 8) : make_uint4(0u, 0u, 0u, 0u);
+    for (int i = 0; i < 4; i++) {
+        const int idx = tid + 256 * i, row = (idx >> 5) & 31, seg = idx & 31;
+        goffs[i] = (uint32_t)((rbeg + row) * NF + seg * 8) * 2u;
+        gl[i] = (uint32_t)(2 * Wg::APB + Wg::grow(row) + seg * 16);
+    }
+    // (as a vector offset, so that the range check sees it: rows before 0 wrap to huge offsets, rows past M - 1 exceed M * 512)
+    const uint32_t aoffs = (uint32_t)(((rbeg - Wg::HALO + a_row) * NF + cit * 16 + a_seg * 8) * 2);
+    const uint32_t al = (uint32_t)(a_part * Wg::APB + Wg::arow(a_row) + a_seg * 16);
+    u32x4 sg[8], sa;
+    auto fetch = [&](int ks) {
+        const int so = ks * (Wg::KR * NF * 2);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            sg[i] = __builtin_amdgcn_raw_buffer_load_b128(gsrc0, goffs[i], so, 0);
+            sg[i + 4] = __builtin_amdgcn_raw_buffer_load_b128(gsrc1, goffs[i], so, 0);
         }
-        const int gr = r0 - Wg::HALO + a_row;
-        sa = (a_unit && gr >= 0 && gr < M) ? *reinterpret_cast<const uint4*>(a_src + (size_t)gr * NF) : make_uint4(0u, 0u, 0u, 0u);
+        sa = __builtin_amdgcn_raw_buffer_load_b128(asrc, a_unit ? aoffs + (uint32_t)so : 0xfffffff0u, 0, 0);
     };
     auto stash = [&](int buf) {
         uint8_t* b = wg_lds + buf * Wg::BUF;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int idx = tid + 256 * i, part = idx >> 10, row = (idx >> 5) & 31, seg = idx & 31;
-            *reinterpret_cast<uint4*>(b + 2 * Wg::APB + part * Wg::GPB + Wg::grow(row) + seg * 16) = sg[i];
+        for (int i = 0; i < 4; i++) {
+            *reinterpret_cast<u32x4*>(b + gl[i]) = sg[i];
+            *reinterpret_cast<u32x4*>(b + Wg::GPB + gl[i]) = sg[i + 4];
         }
-        if (a_unit) *reinterpret_cast<uint4*>(b + a_part * Wg::APB + Wg::arow(a_row) + a_seg * 16) = sa;
+        if (a_unit) *reinterpret_cast<u32x4*>(b + al) = sa;
     };
     fetch(0);
     stash(0);
@@ -818,39 +893,43 @@ __global__ __launch_bounds__(256, 1) void t_wgrad_rs(Parts A, Parts G, float* __
     for (int t = 0; t < 9; t++)
 #pragma unroll
         for (int c = 0; c < 4; c++) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // the two tile rows this lane addresses in a transposed read: k1 = 8g + q and k1 + 4; their board cells
+    // the two tile rows this lane addresses in a transposed read: k1 = 8g + q and k1 + 4; their board cells and, per tap, the
+    // LDS offsets of their source rows (loop-invariant: the tile moves, the lane's place in it does not)
     const int k1 = 8 * g + q;
     int pos1 = k1 % NPOS, pos2 = (k1 + 4) % NPOS;      // (slices start on a board boundary)
-    const uint32_t a_zero = (uint32_t)(Wg::arow(Wg::AR) + p * 8);
-    const uint32_t g_lo = (uint32_t)(2 * Wg::APB + Wg::grow(k1) + (wave * 64 + p * 4) * 2);
-    const uint32_t g_hi = (uint32_t)(2 * Wg::APB + Wg::grow(k1 + 4) + (wave * 64 + p * 4) * 2);
+    const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)wg_lds;   // absolute LDS addresses
+    uint32_t aoff[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        const int sh = Wg::HALO + (t / 3 - 1) * 6 + (t % 3 - 1);   // source tile row = k + sh
+        aoff[t][0] = lbase + (uint32_t)(Wg::arow(k1 + sh) + p * 8);
+        aoff[t][1] = lbase + (uint32_t)(Wg::arow(k1 + 4 + sh) + p * 8);
+    }
+    uint32_t a_zero = lbase + (uint32_t)(Wg::arow(Wg::AR) + p * 8);
+    uint32_t g_lo = lbase + (uint32_t)(2 * Wg::APB + Wg::grow(k1) + (wave * 64 + p * 4) * 2);
+    uint32_t g_hi = lbase + (uint32_t)(2 * Wg::APB + Wg::grow(k1 + 4) + (wave * 64 + p * 4) * 2);
 
+    uint32_t gls[4] = {gl[0] + Wg::BUF, gl[1] + Wg::BUF, gl[2] + Wg::BUF, gl[3] + Wg::BUF}, als = al + Wg::BUF;   // stash targets: the OTHER buffer
     for (int ks = 0; ks < nks; ks++) {
         if (ks + 1 < nks) fetch(ks + 1);
-        const uint8_t* b = wg_lds + (ks & 1) * Wg::BUF;
-        const int y1 = pos1 / 6, x1 = pos1 - 6 * y1, y2 = pos2 / 6, x2 = pos2 - 6 * y2;
-        s16x8 gf[2][4];   // dY fragments [part][co tile]
+        wg_kstep(pos1, pos2, aoff, a_zero, g_lo, g_hi, acc);
+        if (ks + 1 < nks) {
 #pragma unroll
-        for (int part = 0; part < 2; part++)
-#pragma unroll
-            for (int c = 0; c < 4; c++) gf[part][c] = lds_tr8(b + g_lo + part * Wg::GPB + c * 32, b + g_hi + part * Wg::GPB + c * 32);
-#pragma unroll
-        for (int t = 0; t < 9; t++) {
-            const int dy = t / 3 - 1, dx = t % 3 - 1, sh = Wg::HALO + dy * 6 + dx;   // source tile row = k + sh
-            const bool v1 = (unsigned)(y1 + dy) < 7u && (unsigned)(x1 + dx) < 6u, v2 = (unsigned)(y2 + dy) < 7u && (unsigned)(x2 + dx) < 6u;
-            const uint32_t o1 = v1 ? (uint32_t)(Wg::arow(k1 + sh) + p * 8) : a_zero, o2 = v2 ? (uint32_t)(Wg::arow(k1 + 4 + sh) + p * 8) : a_zero;
-            const s16x8 ah = lds_tr8(b + o1, b + o2), am = lds_tr8(b + Wg::APB + o1, b + Wg::APB + o2);
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, am), __builtin_bit_cast(bf16x8, gf[0][c]), acc[t][c], 0, 0, 0);
-                acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, gf[1][c]), acc[t][c], 0, 0, 0);
-                acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, gf[0][c]), acc[t][c], 0, 0, 0);
+            for (int i = 0; i < 4; i++) {
+                *reinterpret_cast<u32x4*>(wg_lds + gls[i]) = sg[i];
+                *reinterpret_cast<u32x4*>(wg_lds + Wg::GPB + gls[i]) = sg[i + 4];
             }
+            if (a_unit) *reinterpret_cast<u32x4*>(wg_lds + als) = sa;
         }
-        pos1 += Wg::KR; if (pos1 >= NPOS) pos1 -= NPOS;
-        pos2 += Wg::KR; if (pos2 >= NPOS) pos2 -= NPOS;
-        if (ks + 1 < nks) stash((ks + 1) & 1);
         __syncthreads();
+        // everything that points into a buffer moves to the other one
+        const uint32_t d = (ks & 1) ? (uint32_t)-Wg::BUF : (uint32_t)Wg::BUF;
+#pragma unroll
+        for (int t = 0; t < 9; t++) { aoff[t][0] += d; aoff[t][1] += d; }
+        a_zero += d; g_lo += d; g_hi += d;
+#pragma unroll
+        for (int i = 0; i < 4; i++) gls[i] -= d;
+        als -= d;
     }
     float* o = out + (size_t)slice * KC * NF;
 #pragma unroll
