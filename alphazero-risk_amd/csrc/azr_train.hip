@@ -743,11 +743,11 @@ __global__ __launch_bounds__(256, 1) void t_conv_rs(Parts A, Parts Bp, float* __
 // rows of one channel per lane.  gfx950's transposed LDS read (ds_read_b64_tr_b16) delivers exactly that from row-major
 // tiles, and because every lane supplies the ADDRESS of one row of a 4-row block, the tap shift and the board-edge mask
 // cost nothing: an out-of-board source row is simply the address of a zero row (no im2col, no register transposes, no masks).
-//   block = one slice of whole boards (the split-K unit) x one 16-channel ci tile; 4 waves x 64 output channels;
-//   per wave 9 taps x 4 co tiles = 36 accumulator tiles: a dY fragment feeds 9 taps, an A fragment 4 co tiles;
-//   per k-step (32 rows) the block stages 32 rows x 256 co of dY and 46 rows (7 halo rows each side) x 16 ci of A, both
-//   parts, double-buffered through registers: one barrier per k-step of 108 MFMAs per wave.
-// Blocks of one slice are 16 apart in blockIdx (same XCD: the slice's dY is fetched into one L2).
+//   block = ONE WAVE = one slice of whole boards (the split-K unit) x one 16-channel ci tile x 64 output channels:
+//   9 taps x 4 co tiles = 36 accumulator tiles; a dY fragment feeds 9 taps, an A fragment 4 co tiles;
+//   per k-step (32 rows) the wave stages its 32 rows x 64 co of dY and 46 rows (7 halo rows each side) x 16 ci of A, both
+//   parts, through registers into its private LDS tile: 108 MFMAs per k-step, no barrier anywhere.
+// Blocks of one slice are NS apart in blockIdx (same XCD: the slice's dY is fetched into one L2).
 // ---------------------------------------------------------------------------------------------------------------------
 struct Wg {
     static constexpr int KR = 32, HALO = 7, AR = KR + 2 * HALO;
@@ -756,12 +756,12 @@ struct Wg {
     // rows, the eight rows cover the 64 banks once — for any tap shift of the A rows too.
     static constexpr int AST = 32;                 // bytes per row of the A tile (16 ci)
     static constexpr int APB = (AR + 1) * AST + (AR / 8) * 128;   // one part: rows and gaps, incl. the zero row (row AR)
-    static constexpr int GST = 544;                // bytes per row of the dY tile (256 co + 32 B pad: 136 banks = 8 mod 64)
+    static constexpr int GST = 160;                // bytes per row of the dY tile (this wave's 64 co + 32 B pad: 40 banks)
     static constexpr int GPB = KR * GST + (KR / 8) * 128;
     __host__ __device__ static constexpr int arow(int r) { return r * AST + (r >> 3) * 128; }
     __host__ __device__ static constexpr int grow(int r) { return r * GST + (r >> 3) * 128; }
     static constexpr int BUF = 2 * APB + 2 * GPB;  // A part 0 | A part 1 | dY part 0 | dY part 1
-    static constexpr int LDS_BYTES = 2 * BUF;
+    static constexpr int LDS_BYTES = BUF;          // ONE buffer: a wave's LDS operations run in program order (see t_wgrad_rs)
 };
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -781,8 +781,7 @@ __device__ __forceinline__ s16x8 lds_tr8(uint32_t a_lo, uint32_t a_hi)
 // compiler reuses one slot and waits for every read in front of its MFMAs), and everything else is kept to the reads
 // themselves, one v_cndmask per A read (valid source row or the zero row: the row addresses are loop-invariant registers,
 // part offsets are instruction immediates) and eight edge tests per k-step whose combinations per tap are scalar.
-// The addresses passed in point into this k-step's buffer (the caller moves them to the other buffer after every k-step:
-// one loop body — two copies of the k-step in one loop made the compiler shuffle all 144 accumulators at the back-edge).
+// (One loop body: two copies of the k-step in one loop made the compiler shuffle all 144 accumulators at the back-edge.)
 template <int T>
 __device__ __forceinline__ void wg_afrag(int y1, int x1, int y2, int x2, const uint32_t (&aoff)[9][2], uint32_t a_zero, s16x8& ah, s16x8& am)
 {
@@ -833,39 +832,49 @@ __device__ __forceinline__ void wg_kstep(int& pos1, int& pos2, const uint32_t (&
     pos2 += Wg::KR; if (pos2 >= NPOS) pos2 -= NPOS;
 }
 
-__global__ __launch_bounds__(256, 1) void t_wgrad_rs(Parts A, Parts G, float* __restrict__ out, int M, int NS, int rows_per_slice)
+// One WAVE per block: a wave's tiles (its 64 co columns of dY, its own copy of the 16-ci A rows) are private, so there is
+// nothing to synchronise with — no barrier, and the four waves of a CU (four blocks, 15 KB of LDS each) drift apart and hide
+// each other's bubbles.  A single LDS buffer suffices: the next tile travels global -> registers while this k-step
+// computes and is stored over the current one AFTER the k-step's last fragment read has been issued — the LDS operations
+// of one wave execute in program order.  Measured per k-step on one box (rocprofv3 kernel time, parts removed): the 108
+// MFMAs 37 us of the 67, the staging 10, the A fragment reads 7: with one wave per SIMD nothing overlaps for free.
+__global__ __launch_bounds__(64, 1) void t_wgrad_rs(Parts A, Parts G, float* __restrict__ out, int M, int NS, int rows_per_slice)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t wg_lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x;
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
-    const int slice = blockIdx.x % NS, cit = blockIdx.x / NS;
+    const int slice = blockIdx.x % NS, rest = blockIdx.x / NS, cit = rest & 15, wq = rest >> 4;   // wq = which 64 co columns
     const int rbeg = slice * rows_per_slice, rend = min(M, rbeg + rows_per_slice);
     const int nks = (rend - rbeg) / Wg::KR;    // whole k-steps: slices are multiples of 16 boards = 21 k-steps
 
-    // zero rows of the A parts (both buffers)
-    for (int i = tid; i < 4 * (Wg::AST / 4); i += 256)
-        reinterpret_cast<uint32_t*>(wg_lds + (i / (Wg::AST / 4) >> 1) * Wg::BUF + (i / (Wg::AST / 4) & 1) * Wg::APB + Wg::arow(Wg::AR))[i % (Wg::AST / 4)] = 0u;
+    // zero rows of the two A parts
+    if (lane < 2 * (Wg::AST / 4))
+        reinterpret_cast<uint32_t*>(wg_lds + (lane / (Wg::AST / 4)) * Wg::APB + Wg::arow(Wg::AR))[lane % (Wg::AST / 4)] = 0u;
 
-    // staging units of this thread: 8 of the dY tile (the same (row, segment) of part 0 and part 1, four times: always inside
-    // the slice) and at most 1 of the A tile (part 0: waves 0, 1; part 1: waves 2, 3; halo rows before row 0 or after row
-    // M - 1 are out of range of the buffer resource and read as 0).  Buffer loads: the k-step advances a scalar offset.
+    // staging units of this lane: 8 of the dY tile (4 (row, 16-byte segment) pairs x 2 parts: always inside the slice) and
+    // up to 4 of the A tile (2 per part; halo rows before row 0 or after row M - 1 are out of range of the buffer resource
+    // and read as 0).  Buffer loads: the k-step advances a scalar offset.
     const __amdgpu_buffer_rsrc_t gsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(G.p[0]), (short)0, M * NF * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t gsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(G.p[1]), (short)0, M * NF * 2, 0x00020000);
-    const int a_part = __builtin_amdgcn_readfirstlane(tid >> 7);
-    const int a_rem = tid & 127, a_row = a_rem >> 1, a_seg = a_rem & 1;
-    const bool a_unit = a_rem < 2 * Wg::AR;
-    const __amdgpu_buffer_rsrc_t asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a_part ? A.p[1] : A.p[0]), (short)0, M * NF * 2, 0x00020000);
-    uint32_t goffs[4], gl[4];
+    const __amdgpu_buffer_rsrc_t asrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A.p[0]), (short)0, M * NF * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t asrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A.p[1]), (short)0, M * NF * 2, 0x00020000);
+    uint32_t goffs[4], gl[4], aoffs[2], al[2];
+    bool a_unit[2];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int idx = tid + 256 * i, row = (idx >> 5) & 31, seg = idx & 31;
-        goffs[i] = (uint32_t)((rbeg + row) * NF + seg * 8) * 2u;
+        const int row = i * 8 + (lane >> 3), seg = lane & 7;
+        goffs[i] = (uint32_t)((rbeg + row) * NF + wq * 64 + seg * 8) * 2u;
         gl[i] = (uint32_t)(2 * Wg::APB + Wg::grow(row) + seg * 16);
     }
-    // (as a vector offset, so that the range check sees it: rows before 0 wrap to huge offsets, rows past M - 1 exceed M * 512)
-    const uint32_t aoffs = (uint32_t)(((rbeg - Wg::HALO + a_row) * NF + cit * 16 + a_seg * 8) * 2);
-    const uint32_t al = (uint32_t)(a_part * Wg::APB + Wg::arow(a_row) + a_seg * 16);
-    u32x4 sg[8], sa;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int v = lane + 64 * j, row = v >> 1, seg = v & 1;
+        a_unit[j] = v < 2 * Wg::AR;
+        // (as a vector offset, so that the range check sees it: rows before 0 wrap to huge offsets, rows past M - 1 exceed M * 512)
+        aoffs[j] = a_unit[j] ? (uint32_t)(((rbeg - Wg::HALO + row) * NF + cit * 16 + seg * 8) * 2) : 0xfffffff0u;
+        al[j] = (uint32_t)(Wg::arow(a_unit[j] ? row : Wg::AR - 1) + seg * 16);
+    }
+    u32x4 sg[8], sa[4];
     auto fetch = [&](int ks) {
         const int so = ks * (Wg::KR * NF * 2);
 #pragma unroll
@@ -873,20 +882,29 @@ __global__ __launch_bounds__(256, 1) void t_wgrad_rs(Parts A, Parts G, float* __
             sg[i] = __builtin_amdgcn_raw_buffer_load_b128(gsrc0, goffs[i], so, 0);
             sg[i + 4] = __builtin_amdgcn_raw_buffer_load_b128(gsrc1, goffs[i], so, 0);
         }
-        sa = __builtin_amdgcn_raw_buffer_load_b128(asrc, a_unit ? aoffs + (uint32_t)so : 0xfffffff0u, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint32_t vo = a_unit[j] ? aoffs[j] + (uint32_t)so : 0xfffffff0u;
+            sa[j] = __builtin_amdgcn_raw_buffer_load_b128(asrc0, vo, 0, 0);
+            sa[j + 2] = __builtin_amdgcn_raw_buffer_load_b128(asrc1, vo, 0, 0);
+        }
     };
-    auto stash = [&](int buf) {
-        uint8_t* b = wg_lds + buf * Wg::BUF;
+    auto stash = [&]() {
+        uint8_t* b = wg_lds;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             *reinterpret_cast<u32x4*>(b + gl[i]) = sg[i];
             *reinterpret_cast<u32x4*>(b + Wg::GPB + gl[i]) = sg[i + 4];
         }
-        if (a_unit) *reinterpret_cast<u32x4*>(b + al) = sa;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            if (a_unit[j]) {
+                *reinterpret_cast<u32x4*>(b + al[j]) = sa[j];
+                *reinterpret_cast<u32x4*>(b + Wg::APB + al[j]) = sa[j + 2];
+            }
     };
     fetch(0);
-    stash(0);
-    __syncthreads();
+    stash();
 
     f32x4 acc[9][4];
 #pragma unroll
@@ -894,7 +912,7 @@ __global__ __launch_bounds__(256, 1) void t_wgrad_rs(Parts A, Parts G, float* __
 #pragma unroll
         for (int c = 0; c < 4; c++) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     // the two tile rows this lane addresses in a transposed read: k1 = 8g + q and k1 + 4; their board cells and, per tap, the
-    // LDS offsets of their source rows (loop-invariant: the tile moves, the lane's place in it does not)
+    // LDS addresses of their source rows (loop-invariant: the tile moves, the lane's place in it does not)
     const int k1 = 8 * g + q;
     int pos1 = k1 % NPOS, pos2 = (k1 + 4) % NPOS;      // (slices start on a board boundary)
     const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)wg_lds;   // absolute LDS addresses
@@ -905,31 +923,16 @@ __global__ __launch_bounds__(256, 1) void t_wgrad_rs(Parts A, Parts G, float* __
         aoff[t][0] = lbase + (uint32_t)(Wg::arow(k1 + sh) + p * 8);
         aoff[t][1] = lbase + (uint32_t)(Wg::arow(k1 + 4 + sh) + p * 8);
     }
-    uint32_t a_zero = lbase + (uint32_t)(Wg::arow(Wg::AR) + p * 8);
-    uint32_t g_lo = lbase + (uint32_t)(2 * Wg::APB + Wg::grow(k1) + (wave * 64 + p * 4) * 2);
-    uint32_t g_hi = lbase + (uint32_t)(2 * Wg::APB + Wg::grow(k1 + 4) + (wave * 64 + p * 4) * 2);
+    const uint32_t a_zero = lbase + (uint32_t)(Wg::arow(Wg::AR) + p * 8);
+    const uint32_t g_lo = lbase + (uint32_t)(2 * Wg::APB + Wg::grow(k1) + p * 8);
+    const uint32_t g_hi = lbase + (uint32_t)(2 * Wg::APB + Wg::grow(k1 + 4) + p * 8);
 
-    uint32_t gls[4] = {gl[0] + Wg::BUF, gl[1] + Wg::BUF, gl[2] + Wg::BUF, gl[3] + Wg::BUF}, als = al + Wg::BUF;   // stash targets: the OTHER buffer
     for (int ks = 0; ks < nks; ks++) {
         if (ks + 1 < nks) fetch(ks + 1);
+        asm volatile("" ::: "memory");   // (the fragment reads below follow this wave's own tile stores in program order ...
         wg_kstep(pos1, pos2, aoff, a_zero, g_lo, g_hi, acc);
-        if (ks + 1 < nks) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                *reinterpret_cast<u32x4*>(wg_lds + gls[i]) = sg[i];
-                *reinterpret_cast<u32x4*>(wg_lds + Wg::GPB + gls[i]) = sg[i + 4];
-            }
-            if (a_unit) *reinterpret_cast<u32x4*>(wg_lds + als) = sa;
-        }
-        __syncthreads();
-        // everything that points into a buffer moves to the other one
-        const uint32_t d = (ks & 1) ? (uint32_t)-Wg::BUF : (uint32_t)Wg::BUF;
-#pragma unroll
-        for (int t = 0; t < 9; t++) { aoff[t][0] += d; aoff[t][1] += d; }
-        a_zero += d; g_lo += d; g_hi += d;
-#pragma unroll
-        for (int i = 0; i < 4; i++) gls[i] -= d;
-        als -= d;
+        asm volatile("" ::: "memory");   //  ... and the stores of the next tile follow the reads)
+        if (ks + 1 < nks) stash();
     }
     float* o = out + (size_t)slice * KC * NF;
 #pragma unroll
@@ -938,7 +941,7 @@ __global__ __launch_bounds__(256, 1) void t_wgrad_rs(Parts A, Parts G, float* __
         for (int c = 0; c < 4; c++)
 #pragma unroll
             for (int e = 0; e < 4; e++)
-                o[(size_t)(t * NF + cit * 16 + 4 * g + e) * NF + wave * 64 + c * 16 + i16] = acc[t][c][e];
+                o[(size_t)(t * NF + cit * 16 + 4 * g + e) * NF + wq * 64 + c * 16 + i16] = acc[t][c][e];
 }
 
 // out[i] = sum_z part[z][i]
@@ -1895,7 +1898,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         // dW = col(input)^T x dY  (implicit im2col, split-K over the M rows)
         if (sb) {
             if (g_conv_rs)
-                hipLaunchKernelGGL(t_wgrad_rs, dim3(16 * c->wg_slices), dim3(256), Wg::LDS_BYTES, st, Parts{{Ap(l - 1).p[0], Ap(l - 1).p[1], nullptr}},
+                hipLaunchKernelGGL(t_wgrad_rs, dim3(64 * c->wg_slices), dim3(64), Wg::LDS_BYTES, st, Parts{{Ap(l - 1).p[0], Ap(l - 1).p[1], nullptr}},
                                    Parts{{c->dyp[0], c->dyp[1], nullptr}}, c->wpart, M, c->wg_slices, c->wg_rows);
             else
                 gemm_sb<true, false, 128, 1, 0, 2>(st, Parts{{Ap(l - 1).p[0], Ap(l - 1).p[1], nullptr}}, KC, Parts{{c->dyp[0], c->dyp[1], nullptr}}, NF, c->wpart,
