@@ -857,10 +857,18 @@ static int engine_init(azr_engine* h, const azr_settings* s);
 
 extern "C" int azr_engine_create(const azr_settings* s, azr_engine** out)
 {
-    if (!s || !out || s->games <= 0 || s->blocks <= 0 || s->mcts_simulations < 0) return AZR_E_INVALID_ARGUMENT;
-    if (s->mcts_threads < 1 || s->mcts_threads > MAX_THREADS) return AZR_E_INVALID_ARGUMENT;
-    if (s->mcts_simulations > 0 && s->mcts_simulations < s->mcts_threads) return AZR_E_INVALID_ARGUMENT;  // count = S - S % T would be 0
-    *out = nullptr;
+    if (!out) { g_create_err = "azr_engine_create: out is NULL"; return AZR_E_INVALID_ARGUMENT; }
+    *out = nullptr;   // first: every failure below leaves NULL behind and its reason in g_create_err
+    auto bad = [&](const std::string& why) { g_create_err = "azr_engine_create: " + why; return (int)AZR_E_INVALID_ARGUMENT; };
+    if (!s) return bad("settings is NULL");
+    if (s->games <= 0) return bad("games = " + std::to_string(s->games) + " (need > 0)");
+    if (s->blocks <= 0) return bad("blocks = " + std::to_string(s->blocks) + " (need > 0)");
+    if (s->mcts_simulations < 0) return bad("mcts_simulations = " + std::to_string(s->mcts_simulations) + " (need >= 0)");
+    if (s->mcts_threads < 1 || s->mcts_threads > MAX_THREADS)
+        return bad("mcts_threads = " + std::to_string(s->mcts_threads) + " (need 1.." + std::to_string(MAX_THREADS) + ")");
+    if (s->mcts_simulations > 0 && s->mcts_simulations < s->mcts_threads)   // count = S - S % T would be 0
+        return bad("mcts_simulations = " + std::to_string(s->mcts_simulations) + " < mcts_threads = " + std::to_string(s->mcts_threads) +
+                   " (S - S % T simulations would be none)");
     // node indices are 16-bit (azr_tree.hpp): a pool above 65 534 nodes per game cannot be addressed.  Rejected, not
     // clamped: a silently smaller pool would change which expansions are dropped.
     const long long want_nodes = s->node_capacity > 0 ? (long long)s->node_capacity : 16ll * (s->mcts_simulations + 1);

@@ -1794,7 +1794,7 @@ inline dim3 grid1(size_t n, int bs) { return dim3((unsigned)((n + bs - 1) / bs))
 // communicator's own stream and returns when the result is in place.
 int dp_allreduce(azr_engine* h, TrainCtx* c, void* dev, size_t count, int dtype)
 {
-    if (c->world <= 1) return AZR_OK;
+    if (!c->ar) return AZR_OK;
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const int rc = c->ar(c->ar_ctx, dev, count, dtype);
@@ -1809,7 +1809,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     const int M = c->M, B = c->blocks, R = c->R, BS = c->BS;
     // data-parallel: BS / M are this rank's shard, BSg / Mg the whole minibatch every statistic and mean refers to
     const int W = c->world, BSg = BS * W, Mg = M * W;
-    const bool dp = W > 1;
+    const bool dp = c->ar != nullptr;   // a callback was supplied: the data-parallel code path, also with one rank (every sum is then the identity)
     const float gscale = 1.0f / (float)W;
     // sums over the batch: [local partials -> one slab] -> all-reduce over the ranks -> the finalize kernel reads the slab
     auto reduce_parts = [&](int K) -> int {
@@ -1941,7 +1941,7 @@ int run_step(azr_engine* h, TrainCtx* c)
 {
     static const bool use_graph = getenv("AZR_TRAIN_GRAPH") && atoi(getenv("AZR_TRAIN_GRAPH")) != 0;
     c->step++;
-    if (!use_graph || c->world > 1) {   // (host callbacks of the data-parallel step cannot be captured)
+    if (!use_graph || c->ar) {   // (host callbacks of the data-parallel step cannot be captured)
         hipLaunchKernelGGL(t_gather, dim3(c->BS), dim3(64), 0, h->stream, c->rec, c->perm, (const int*)c->cur, c->BS, c->in88, c->pit, c->zt);
         return train_step(h, c, c->loss + 2);
     }

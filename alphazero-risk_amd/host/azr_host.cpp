@@ -471,18 +471,28 @@ SelfPlayReport AlphaZeroTrainer::generateTrainData(std::shared_ptr<AlphaZeroNNGr
     std::vector<NNTrainDataStorage> storageGroup(P);
     std::vector<SelfPlayReport> rep(P);
     std::vector<std::thread> threads;
+    // GPU i's seed stream: base + i * 2^24 + (games this GPU has started in earlier iterations) — no game of any
+    // (iteration, GPU) pair is ever replayed.  Shares, seeds and the stream positions are fixed HERE, by the parent, before
+    // any thread exists: the threads only read their own copies.
+    if (selfPlayStarted.size() < (size_t)P) selfPlayStarted.resize(P, 0);
+    std::vector<uint64_t> shares(P);
+    std::vector<uint32_t> seeds(P);
+    for (int i = 0; i < P; i++) {
+        shares[i] = target / P + ((uint64_t)i < target % P ? 1 : 0);
+        seeds[i] = SETTINGS.BASE_SEED + (uint32_t)i * (1u << 24) + (uint32_t)selfPlayStarted[i];
+        selfPlayStarted[i] += shares[i];
+    }
+    std::vector<std::string> failed(P);   // a thread's error text; raised after join() (a throw inside a std::thread terminates)
     auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < P; i++) {
-        threads.emplace_back([&, i]() {  // one self-play thread per GPU (alphazero_trainer.cpp:48-57)
+        const uint64_t share = shares[i];
+        const uint32_t seed = seeds[i];
+        if (share == 0) continue;
+        threads.emplace_back([&, i, share, seed]() {  // one self-play thread per GPU (alphazero_trainer.cpp:48-57)
+          try {
             Engine& e = *generate->getNN(i)->engine;
-            const uint64_t share = target / P + ((uint64_t)i < target % P ? 1 : 0);
-            if (share == 0) return;
-            // GPU i's seed stream: base + i * 2^24 + (games this GPU has started in earlier iterations) — no game of any
-            // (iteration, GPU) pair is ever replayed.  Exactly `share` games are started and every one is played to its
-            // end (Counter::hasNext over TRAIN_ITERATION_GAMES, alphazero_trainer.cpp:83).
-            if (selfPlayStarted.size() < (size_t)P) selfPlayStarted.resize(P, 0);
-            const uint32_t seed = SETTINGS.BASE_SEED + (uint32_t)i * (1u << 24) + (uint32_t)selfPlayStarted[i];
-            selfPlayStarted[i] += share;
+            // exactly `share` games are started and every one is played to its end (Counter::hasNext over
+            // TRAIN_ITERATION_GAMES, alphazero_trainer.cpp:83)
             e.check(azr_selfplay_start_games(e.h, seed, share), "selfplay_start_games");
             azr_counters c{};
             std::vector<uint8_t> buf((size_t)e.games * 512 * AZR_RECORD_BYTES);
@@ -500,9 +510,16 @@ SelfPlayReport AlphaZeroTrainer::generateTrainData(std::shared_ptr<AlphaZeroNNGr
             }
             rep[i].games = c.games_finished; rep[i].decisions = c.decisions; rep[i].simulations = c.simulations;
             rep[i].samples = storageGroup[i].data.size(); rep[i].errors = c.errors;
+          } catch (const std::exception& ex) {
+            failed[i] = ex.what()[0] ? ex.what() : "unknown error";
+          } catch (...) {
+            failed[i] = "unknown error";
+          }
         });
     }
     for (auto& t : threads) t.join();
+    for (int i = 0; i < P; i++)
+        if (!failed[i].empty()) throw std::runtime_error("self-play on gpu " + std::to_string(i) + ": " + failed[i]);
     SelfPlayReport tot;
     tot.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const size_t before = trainStorage.data.size();

@@ -181,6 +181,7 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
             import torch
             new_recs = shard_mod.gather_records(torch.from_numpy(new_recs).to(cdev), dist).cpu().numpy()
             c = shard_mod.reduce_counters({k: c[k] for k in ("games_finished", "simulations")}, dist, device=cdev)
+            log(f"Record exchange: all_gather + counter all_reduce, backend {dist.get_backend()}, tensors on {cdev}, world {world}")
         dt = time.time() - t0
         log(f"Generated {len(new_recs)} new samples for total {len(records) + len(new_recs)}  "
             f"[{c['games_finished']} games, {c['simulations'] / dt:.0f} simulations/s, {c['games_finished'] / dt:.2f} games/s]")
@@ -199,9 +200,10 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
             # data-parallel optimiser step: every rank takes 1/world of each minibatch (same shuffle stream everywhere);
             # batch statistics, losses and the gradient vector are all-reduced (RCCL over xGMI), every rank takes the
             # same Adam step — no weight broadcast
-            hist, shuffle_state = new.train_dp(records, a.e, shard_mod.make_allreduce(dist, cdev != "cpu"), rank, world,
+            hist, shuffle_state = new.train_dp(records, a.e, shard_mod.make_allreduce(dist, cdev != "cpu", a.device), rank, world,
                                                batch_size=a.bs, rng_state=shuffle_state)
             hist = [h for h in hist if not np.isnan(h[0])]
+            log(f"Data-parallel optimiser step: all-reduces on {'device buffers, backend ' + dist.get_backend() if cdev != 'cpu' else 'host copies (gloo rehearsal)'}")
             if rank == 0:
                 nn_log.write(nn_training_line(hist)); nn_log.flush()
         else:
@@ -211,6 +213,7 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
                 nn_log.write(nn_training_line(hist)); nn_log.flush()
             if dist is not None:   # ... and the others receive its weights
                 w = shard_mod.broadcast_flat(new.get_weights(), dist, src=0, device=cdev)
+                log(f"Weight broadcast from rank 0: backend {dist.get_backend()}, tensor on {cdev}")
                 if rank != 0:
                     new.set_weights(w)
         steps = a.e * (len(records) // a.bs)
@@ -283,18 +286,24 @@ def main():
                          "(the reference's AlphaZeroNNGroup::train), -1 (default) = data-parallel when --bs / world >= 512")
     a = ap.parse_args()
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1:
+    if world == 1 and not shard_mod.force_dist():
         learn(a)
         return
+    # (AZR_FORCE_DIST=1 with one rank: the whole multi-rank code path — RCCL gather, counter all-reduce, weight broadcast or
+    # data-parallel optimiser step — on a single GPU)
     import torch
     import torch.distributed as dist
     backend = os.environ.get("AZR_LEARN_BACKEND", "nccl")   # "gloo": rehearsal of the N > 1 path on fewer GPUs than ranks
     ndev = torch.cuda.device_count()
     a.device = local % max(ndev, 1)
+    torch.cuda.set_device(a.device)   # torch's HIP runtime first, then the C-ABI library's; also under gloo: the
+    torch.cuda.init()                 # all-reduce callback aliases engine buffers on THIS device
+    for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517")):
+        os.environ.setdefault(k, v)
     if backend == "nccl":
-        torch.cuda.set_device(a.device)   # torch's HIP runtime first, then the C-ABI library's
-        torch.cuda.init()
-    dist.init_process_group(backend)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", a.device))
+    else:
+        dist.init_process_group(backend)
     try:
         learn(a, dist=dist, rank=rank, world=world, cdev=f"cuda:{a.device}" if backend == "nccl" else "cpu")
     finally:

@@ -6,6 +6,8 @@ The only exchange is the gather of finished (s, pi, z) records (reference: train
 alphazero_trainer.cpp:59-62) — here an all_gather over torch.distributed (backend "nccl" = RCCL over xGMI on
 the GPU box, "gloo" in the CPU tests).
 """
+import os
+
 import numpy as np
 
 RECORD_BYTES = 265
@@ -26,12 +28,22 @@ def selfplay_seed(base_seed, rank, games_started):
     return (int(base_seed) + int(rank) * SEED_STRIDE + int(games_started)) & 0xFFFFFFFF
 
 
+def force_dist():
+    """AZR_FORCE_DIST=1: a world of ONE rank still goes through every collective (all_gather, all_reduce, broadcast) instead
+    of the single-process shortcuts — how the RCCL code path is exercised on a box with one GPU."""
+    return os.environ.get("AZR_FORCE_DIST", "0") not in ("", "0")
+
+
+def _active(dist):
+    return dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_dist())
+
+
 def gather_records(records, dist=None, device=None):
     """all ranks contribute a uint8 tensor [n_r, 265]; every rank gets the concatenation in rank order.
     Padded all_gather: counts first, then buffers padded to the maximum count."""
     import torch
 
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active(dist):
         return records
     world = dist.get_world_size()
     dev = records.device if device is None else device
@@ -53,7 +65,7 @@ def reduce_counters(counters, dist=None, device="cpu"):
 
     keys = sorted(counters)
     t = torch.tensor([counters[k] for k in keys], dtype=torch.int64, device=device)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active(dist):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return {k: int(v) for k, v in zip(keys, t.tolist())}
 
@@ -69,7 +81,7 @@ def broadcast_flat(flat, dist=None, src=0, device="cpu"):
     same size on every rank; returns the received ndarray."""
     import torch
 
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active(dist):
         return flat
     t = torch.from_numpy(np.ascontiguousarray(flat, np.float32)).to(device)
     dist.broadcast(t, src=src)
@@ -84,23 +96,30 @@ class _DevicePtr:
                                          "version": 2, "strides": None}
 
 
-def make_allreduce(dist, on_device):
+def make_allreduce(dist, on_device, device_index=None):
     """the callback azr_nn_train_dp wants: sum a device buffer of the engine over the ranks, in place.
     on_device (backend "nccl" = RCCL over xGMI): the collective runs on the buffer itself.  Otherwise (gloo rehearsal, ranks
-    sharing a GPU): staged through a host tensor.  Returns when the result is in place."""
+    sharing a GPU): staged through a host tensor.  device_index = the ENGINE's HIP device (default: torch's current device);
+    the tensor must alias the engine's buffer there — checked, because a silent copy to another device would leave the
+    engine with its un-reduced sums.  Returns when the result is in place."""
     import torch
 
     _one_hip_runtime()
+    idx = torch.cuda.current_device() if device_index is None else int(device_index)
+    dev = torch.device("cuda", idx)
 
     def allreduce(ptr, count, dtype):
-        t = torch.as_tensor(_DevicePtr(ptr, count, dtype), device="cuda")
-        if on_device:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        else:
-            c = t.cpu()
-            dist.all_reduce(c, op=dist.ReduceOp.SUM)
-            t.copy_(c)
-        torch.cuda.synchronize()
+        with torch.cuda.device(dev):
+            t = torch.as_tensor(_DevicePtr(ptr, count, dtype), device=dev)
+            if t.data_ptr() != int(ptr) or t.device.index != idx:
+                raise RuntimeError(f"make_allreduce: tensor at {t.data_ptr():#x} on {t.device} does not alias the engine buffer {int(ptr):#x} on cuda:{idx}")
+            if on_device:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            else:
+                c = t.cpu()
+                dist.all_reduce(c, op=dist.ReduceOp.SUM)
+                t.copy_(c)
+            torch.cuda.synchronize(dev)
 
     return allreduce
 

@@ -100,18 +100,54 @@ def spawn_ranks(a, argv):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    import tempfile
+    import threading
+
+    procs, errs = [], []
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        # rank 0's stdout is the result line; every other rank's stdout + everybody's stderr is kept for the failure report
+        errs.append(tempfile.TemporaryFile())
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
+                                      stdout=subprocess.PIPE if r == 0 else errs[-1], stderr=errs[-1]))
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()   # rank 0's pipe is drained while ALL ranks are watched
+    deadline = time.monotonic() + float(os.environ.get("AZR_BENCH_DEADLINE_S", "3000"))
+    why = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        if any(rc not in (None, 0) for rc in rcs):
+            why = "a rank failed"
+        elif time.monotonic() > deadline:
+            why = "deadline passed"
+        if why:   # the survivors would wait in a collective for ever: end them (terminate, then kill)
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_end = time.monotonic() + 10
+            while time.monotonic() < t_end and any(p.poll() is None for p in procs):
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            rcs = [p.wait() for p in procs]
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    out = b"".join(chunks)
     sys.stdout.write(out.decode())
     sys.stdout.flush()
-    if any(rcs):
-        raise SystemExit(f"bench.py: rank exit codes {rcs}")
+    if why or any(rcs):
+        for r, f in enumerate(errs):
+            f.seek(0)
+            tail = f.read().decode(errors="replace")[-4000:]
+            if tail.strip():
+                sys.stderr.write(f"---- rank {r} (exit code {rcs[r]}) ----\n{tail}\n")
+        raise SystemExit(f"bench.py: {why or 'a rank failed'}; rank exit codes {rcs}")
     line = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
     if not line or json.loads(line[-1]).get("n_gpus") != a.gpus:
         raise SystemExit("bench.py: rank 0 did not report n_gpus == --gpus")
@@ -121,6 +157,7 @@ def run_config(ctx, games, sims, threads, steps, warmup, tail):
     """K steps of one configuration on this rank's GPU; returns the per-rank measurements (reduced by the caller)"""
     a, pkg, shard, torch, dist = ctx["a"], ctx["pkg"], ctx["shard"], ctx["torch"], ctx["dist"]
     rank, world, local, dev, cdev = ctx["rank"], ctx["world"], ctx["local"], ctx["dev"], ctx["cdev"]
+    use_dist = ctx["use_dist"]   # world > 1, or AZR_FORCE_DIST=1: a one-rank world still goes through every collective
     passes_per_step = sims // threads + 1   # setRootState's root expansion + (S - S % T) / T lock-stepped rounds
     eng = pkg.Engine(games, blocks=a.blocks, sims=sims, dtype=pkg.NET_BF16 if a.dtype == "bf16" else pkg.NET_F32,
                      device=local, threads=threads)
@@ -135,7 +172,7 @@ def run_config(ctx, games, sims, threads, steps, warmup, tail):
     def barrier():
         torch.cuda.synchronize()
         eng.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -169,7 +206,7 @@ def run_config(ctx, games, sims, threads, steps, warmup, tail):
             "records_dropped"]
     tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     tot = torch.tensor([delta[k] for k in keys], dtype=torch.int64, device=cdev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     dt = float(tmax.item())
@@ -188,7 +225,7 @@ def run_config(ctx, games, sims, threads, steps, warmup, tail):
         el = time.perf_counter() - t_start
         fin = torch.tensor([ct["games_finished"], ct["samples"], ct["simulations"]], dtype=torch.float64, device=cdev)
         elt = torch.tensor([el], dtype=torch.float64, device=cdev)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(fin, op=dist.ReduceOp.SUM)
             dist.all_reduce(elt, op=dist.ReduceOp.MAX)
         gf, smp, sm = fin.tolist()
@@ -201,17 +238,18 @@ def run_config(ctx, games, sims, threads, steps, warmup, tail):
         barrier()
         tg = time.perf_counter()
         recs = shard.device_records_to_torch(eng, dev)
-        allrecs = shard.gather_records(recs if cdev == dev else recs.to(cdev), dist if world > 1 else None)
+        allrecs = shard.gather_records(recs if cdev == dev else recs.to(cdev), dist if use_dist else None)
         barrier()
         gms = 1e3 * (time.perf_counter() - tg)
         gt = torch.tensor([gms], dtype=torch.float64, device=cdev)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(gt, op=dist.ReduceOp.MAX)
         exchange = {"records_gathered": int(allrecs.shape[0]), "bytes": int(allrecs.shape[0]) * 265,
                     "records_this_rank": int(recs.shape[0]), "gather_ms": float(gt.item()),
                     "self_play_window_s": el, "fraction_of_window": float(gt.item()) * 1e-3 / el,
+                    "gathered_on": str(allrecs.device),
                     "collective": "all_gather (counts) + padded all_gather (records), backend %s" % ctx["backend"]
-                                  if world > 1 else "none at N = 1 (device copy of the record ring only)"}
+                                  if use_dist else "none at N = 1 (device copy of the record ring only)"}
         assert ct["records_dropped"] == 0, "records were dropped: raise sample_capacity"
     eng.close()
 
@@ -308,8 +346,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cdev = dev if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("AZR_FORCE_DIST", "0") not in ("", "0")
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:   # AZR_FORCE_DIST=1: the N > 1 code path (RCCL collectives on device tensors) with one rank
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -318,7 +363,7 @@ def main():
     pkg = importlib.import_module("alphazero-risk_amd")
     shard = importlib.import_module("alphazero-risk_amd.shard")
     ctx = dict(a=a, pkg=pkg, shard=shard, torch=torch, dist=dist, rank=rank, world=world, local=local, dev=dev, cdev=cdev,
-               backend=backend)
+               backend=backend, use_dist=use_dist)
     head = run_config(ctx, a.games, a.sims, a.threads, a.steps, a.warmup, tail=not a.no_full_games)
     extras = []
     if world == 1 and not a.no_extra:
@@ -341,7 +386,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.blocks, a.sims, a.threads)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -122,7 +122,8 @@ int azr_nn_train(azr_engine* h, const void* rec265_host, size_t n, int epochs, i
  * (azr_nn_param_count floats) — is summed over the ranks through `allreduce`: in place on DEVICE memory of this GPU,
  * dtype 0 = float32, 1 = float64, return 0 on success; the engine's stream is idle while it runs.  All ranks then take the
  * same Adam step, so their weights stay equal without a broadcast, and equal the single-GPU step's up to summation
- * order.  world = 1 is azr_nn_train. */
+ * order.  world = 1 with allreduce == NULL is azr_nn_train; world = 1 WITH a callback runs the data-parallel code path on one
+ * rank (every all-reduce is the identity): the single-GPU rehearsal of the RCCL path. */
 typedef int (*azr_allreduce_fn)(void* ctx, void* device_ptr, size_t count, int dtype);
 int azr_nn_train_dp(azr_engine* h, const void* rec265_host, size_t n, int epochs, int batch_size, uint32_t* shuffle_rng_state,
                     int rank, int world, azr_allreduce_fn allreduce, void* ctx, float* loss_pi_host, float* loss_v_host);

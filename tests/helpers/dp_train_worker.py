@@ -23,7 +23,11 @@ def main():
     blocks, bs, n, epochs = int(os.environ.get("DP_BLOCKS", "2")), int(os.environ.get("DP_BS", "64")), int(os.environ.get("DP_N", "200")), 2
     torch.cuda.set_device(0)
     torch.cuda.init()
-    dist.init_process_group("gloo")
+    backend = os.environ.get("DP_BACKEND", "gloo")   # "nccl" = RCCL: the all-reduces run on the engine's device buffers themselves
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     import azr_testlib as T
     P = importlib.import_module("alphazero-risk_amd")
@@ -39,7 +43,7 @@ def main():
     pi /= pi.sum(1, keepdims=True)
     rec[:, 93:265] = pi.view(np.uint8).reshape(n, 172)
 
-    ar = shard.make_allreduce(dist, on_device=False)
+    ar = shard.make_allreduce(dist, on_device=(backend == "nccl"), device_index=0)
     res = {}
     for tag, nn, ep in (("one", bs, 1), ("multi", n, epochs)):   # one single step (tight comparison), then 2 epochs x 3 steps
         eng = P.Engine(4, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64)
@@ -54,12 +58,15 @@ def main():
         w_dp, g_dp = eng.get_weights(), eng.train_grads()
         bad = 0
         try:   # a minibatch that does not split evenly over the ranks is refused
-            eng.train_dp(rec[:nn], 1, counted, rank, world, rng_state=1, batch_size=bs + 1)
+            if world > 1:
+                eng.train_dp(rec[:nn], 1, counted, rank, world, rng_state=1, batch_size=bs + 1)
         except P.AzrError as e:
             bad += e.code == 1
         eng.close()
-        allw = [torch.zeros(len(w_dp)) for _ in range(world)]
-        dist.all_gather(allw, torch.from_numpy(w_dp))
+        cdev = torch.device("cuda", 0) if backend == "nccl" else torch.device("cpu")
+        allw = [torch.zeros(len(w_dp), device=cdev) for _ in range(world)]
+        dist.all_gather(allw, torch.from_numpy(w_dp).to(cdev))
+        allw = [x.cpu() for x in allw]
         if rank == 0:
             ref = P.Engine(4, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64)
             ref.set_weights(flat)
@@ -71,7 +78,7 @@ def main():
                         f"{tag}_w_all": np.stack([x.numpy() for x in allw]), f"{tag}_calls": np.array(calls, np.int64), f"{tag}_refused": bad,
                         f"{tag}_steps": ep * (nn // bs)})
     if rank == 0:
-        np.savez(out, w0=flat, world=world, **res)
+        np.savez(out, w0=flat, world=world, backend=backend, **res)
     dist.barrier()
     dist.destroy_process_group()
 
