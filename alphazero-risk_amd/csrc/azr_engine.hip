@@ -1336,7 +1336,7 @@ extern "C" int azr_selfplay_run(azr_engine* h, int passes)
     }
     SYNC(h);
     double tn = 0, tt = 0, tw = 0;
-    const bool tower_timed = h->cfg.net_dtype == AZR_NET_BF16;
+    const bool tower_timed = h->cfg.net_dtype == AZR_NET_BF16 || h->cfg.net_dtype == AZR_NET_F32X;   // one kernel = one net forward, bracketed by events
     for (int i = 0; i < k; i++) {
         float a = 0, b = 0, c = 0;
         HIPCHK(h, hipEventElapsedTime(&a, h->ev[3 * i + 0], h->ev[3 * i + 1]));

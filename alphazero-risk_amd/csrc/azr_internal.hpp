@@ -89,6 +89,10 @@ struct NetDev {
     const float* head; // head section of d_flat
     // bf16 MFMA path
     void* bf16ctx;      // azr_net_bf16.hip: packed weight fragments + tower output buffer
+    void* fxctx;        // azr_tower_fx.hip (AZR_NET_F32X): packed fp16-pair weight fragments
+    // azr_nn_predict staging, created by the first call: device [G] x (96 B in | 44 floats pi | 1 float v), the same in pinned host memory
+    uint8_t* pred_dev;
+    uint8_t* pred_host;
     // activations (fp32 path)
     float* actX;       // [G][42][256]
     float* actT;       // [G][42][256]
@@ -126,6 +130,11 @@ int net_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, floa
 int net_forward_ex(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st);
 size_t net_param_count(int blocks);
 void net_init_random(float* flat, int blocks, uint64_t seed);
+// NET_F32X (azr_tower_fx.hip)
+int net_fx_alloc(azr_engine* h);
+void net_fx_free(azr_engine* h);
+int net_fx_upload(azr_engine* h, const float* fold_host);
+int net_fx_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st);
 // train (azr_train.hip)
 void train_free(azr_engine* h);
 }  // namespace azr

@@ -287,6 +287,9 @@ int azr::net_alloc(azr_engine* h)
         HIPCHK(h, hipMalloc((void**)&n.actT, (size_t)h->d.G * h->d.T * NPOS * NF * sizeof(float)));
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_f32), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       FRAME * NF * (int)sizeof(float)));
+    } else if (h->cfg.net_dtype == AZR_NET_F32X) {
+        int rc = net_fx_alloc(h);
+        if (rc) return rc;
     } else {
         int rc = net_bf16_alloc(h);
         if (rc) return rc;
@@ -302,6 +305,10 @@ void azr::net_free(azr_engine* h)
     if (h->net.actX) hipFree(h->net.actX);
     if (h->net.actT) hipFree(h->net.actT);
     net_bf16_free(h);
+    net_fx_free(h);
+    if (h->net.pred_dev) hipFree(h->net.pred_dev);
+    if (h->net.pred_host) hipHostFree(h->net.pred_host);
+    h->net.pred_dev = h->net.pred_host = nullptr;
     h->net.head = nullptr;
 }
 
@@ -338,6 +345,10 @@ int azr::net_upload(azr_engine* h)
     h->net.head = x->d_flat + off_heads(B);
     if (h->cfg.net_dtype == AZR_NET_BF16) {
         int rc = net_bf16_upload(h);
+        if (rc) return rc;
+    }
+    if (h->cfg.net_dtype == AZR_NET_F32X) {
+        int rc = net_fx_upload(h, fold.data());
         if (rc) return rc;
     }
     h->weights_set = true;
@@ -388,6 +399,7 @@ int azr::net_forward_ex(azr_engine* h, const uint8_t* d_in88, int in_stride, int
         if (n > h->d.G * h->d.T) { h->err = "net_forward: batch larger than the fp32 activation buffers"; return AZR_E_INVALID_ARGUMENT; }
         return net_f32_forward(h, d_in88, in_stride, n, d_pi, d_v, d_map, st);
     }
+    if (h->cfg.net_dtype == AZR_NET_F32X) return net_fx_forward(h, d_in88, in_stride, n, d_pi, d_v, d_map, st);
     return net_bf16_forward(h, d_in88, in_stride, n, d_pi, d_v, d_map, st);
 }
 
@@ -466,21 +478,34 @@ extern "C" int azr_nn_predict(azr_engine* h, const void* in88, int n, float* pi,
     ENTER(h);
     if (!h->weights_set) { h->err = "azr_nn_predict: no weights"; return AZR_E_STATE; }
     if (!in88 || n < 0 || (!pi && !v)) return AZR_E_INVALID_ARGUMENT;
+    // batches of up to G boards through staging buffers that live as long as the handle (pinned host side: the copies are
+    // real async DMA, no allocation in the call path — the reference's predict() is timed per call, alphazero_gpu_cluster.cpp:54-65)
     const int G = h->d.G;
-    uint8_t* d_in = nullptr; float* d_pi = nullptr; float* d_v = nullptr;
-    HIPCHK(h, hipMalloc((void**)&d_in, (size_t)G * LEAF_STRIDE));
-    HIPCHK(h, hipMalloc((void**)&d_pi, (size_t)G * PI_STRIDE * 4));
-    HIPCHK(h, hipMalloc((void**)&d_v, (size_t)G * 4));
+    const size_t in_b = (size_t)G * LEAF_STRIDE, pi_b = (size_t)G * PI_STRIDE * 4, v_b = (size_t)G * 4;
+    if (!h->net.pred_dev) {
+        HIPCHK(h, hipMalloc((void**)&h->net.pred_dev, in_b + pi_b + v_b));
+        HIPCHK(h, hipMemsetAsync(h->net.pred_dev, 0, in_b + pi_b + v_b, h->stream));
+        HIPCHK(h, hipHostMalloc((void**)&h->net.pred_host, in_b + pi_b + v_b, hipHostMallocDefault));
+        memset(h->net.pred_host, 0, in_b + pi_b + v_b);
+    }
+    uint8_t* d_in = h->net.pred_dev;
+    float* d_pi = reinterpret_cast<float*>(h->net.pred_dev + in_b);
+    float* d_v = reinterpret_cast<float*>(h->net.pred_dev + in_b + pi_b);
+    uint8_t* s_in = h->net.pred_host;
+    float* s_pi = reinterpret_cast<float*>(h->net.pred_host + in_b);
+    float* s_v = reinterpret_cast<float*>(h->net.pred_host + in_b + pi_b);
     int rc = AZR_OK;
     for (int base = 0; base < n && rc == AZR_OK; base += G) {
         const int m = n - base < G ? n - base : G;
-        hipMemcpy2DAsync(d_in, LEAF_STRIDE, (const uint8_t*)in88 + (size_t)base * 88, 88, 88, m, hipMemcpyHostToDevice, h->stream);
+        for (int i = 0; i < m; i++) memcpy(s_in + (size_t)i * LEAF_STRIDE, (const uint8_t*)in88 + (size_t)(base + i) * 88, 88);
+        HIPCHK(h, hipMemcpyAsync(d_in, s_in, (size_t)m * LEAF_STRIDE, hipMemcpyHostToDevice, h->stream));
         rc = net_forward(h, d_in, LEAF_STRIDE, m, d_pi, d_v);
         if (rc) break;
-        if (pi) hipMemcpy2DAsync(pi + (size_t)base * 43, 43 * 4, d_pi, PI_STRIDE * 4, 43 * 4, m, hipMemcpyDeviceToHost, h->stream);
-        if (v) hipMemcpyAsync(v + base, d_v, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream);
-        if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "azr_nn_predict: stream error"; rc = AZR_E_HIP; }
+        if (pi) HIPCHK(h, hipMemcpyAsync(s_pi, d_pi, (size_t)m * PI_STRIDE * 4, hipMemcpyDeviceToHost, h->stream));
+        if (v) HIPCHK(h, hipMemcpyAsync(s_v, d_v, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
+        if (hipStreamSynchronize(h->stream) != hipSuccess) { (void)hipGetLastError(); h->err = "azr_nn_predict: stream error"; rc = AZR_E_HIP; break; }
+        if (pi) for (int i = 0; i < m; i++) memcpy(pi + (size_t)(base + i) * 43, s_pi + (size_t)i * PI_STRIDE, 43 * 4);
+        if (v) memcpy(v + base, s_v, (size_t)m * 4);
     }
-    hipFree(d_in); hipFree(d_pi); hipFree(d_v);
     return rc;
 }

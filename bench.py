@@ -153,18 +153,22 @@ def spawn_ranks(a, argv):
         raise SystemExit("bench.py: rank 0 did not report n_gpus == --gpus")
 
 
-def run_config(ctx, games, sims, threads, steps, warmup, tail):
+def run_config(ctx, games, sims, threads, steps, warmup, tail, dtype=None):
     """K steps of one configuration on this rank's GPU; returns the per-rank measurements (reduced by the caller)"""
     a, pkg, shard, torch, dist = ctx["a"], ctx["pkg"], ctx["shard"], ctx["torch"], ctx["dist"]
+    dtype = dtype or a.dtype
     rank, world, local, dev, cdev = ctx["rank"], ctx["world"], ctx["local"], ctx["dev"], ctx["cdev"]
     use_dist = ctx["use_dist"]   # world > 1, or AZR_FORCE_DIST=1: a one-rank world still goes through every collective
     passes_per_step = sims // threads + 1   # setRootState's root expansion + (S - S % T) / T lock-stepped rounds
-    eng = pkg.Engine(games, blocks=a.blocks, sims=sims, dtype=pkg.NET_BF16 if a.dtype == "bf16" else pkg.NET_F32,
+    eng = pkg.Engine(games, blocks=a.blocks, sims=sims, dtype={"bf16": pkg.NET_BF16, "f32": pkg.NET_F32, "f32x": pkg.NET_F32X}[dtype],
                      device=local, threads=threads)
     eng.init_random(20260002)
     eng.selfplay_start(shard.rank_base_seed(20260001, rank))
     tower_kernel_name = "fp32 conv chain"
-    if a.dtype == "bf16":   # the tile plan of this configuration's launches (G x T leaf slots), from the library itself
+    if dtype == "f32x":
+        tower_kernel_name = (f"k_tower_fx<2> x {(games * threads + 1) // 2} workgroups of 2 boards (one whole net forward at fp32-equivalent precision: "
+                             "fp16-pair operands, 3 MFMA passes per conv layer, fp32 accumulate / epilogue / residual / heads, one launch)")
+    if dtype == "bf16":   # the tile plan of this configuration's launches (G x T leaf slots), from the library itself
         nb, wgs = eng.tower_plan(games * threads)
         tower_kernel_name = (f"k_tower_sb<{nb}>" if nb > 1 else "k_tower_bf16<1>") + \
             f" x {wgs} workgroups of {nb} board(s) (one whole net forward of the G x T leaf slots: stem + 2B conv layers + both heads, one launch)"
@@ -259,13 +263,13 @@ def run_config(ctx, games, sims, threads, steps, warmup, tail):
     # algorithmic work of one launch = the leaves that were actually waiting for the net (idle slots are not counted)
     leaves_per_launch = tot["evaluations"] / max(1, npass * world)
     achieved = leaves_per_launch * fps / net_s if net_s > 0 else 0.0
-    peak = PEAK_BF16 if a.dtype == "bf16" else PEAK_F32
+    peak = PEAK_F32 if dtype == "f32" else PEAK_BF16   # f32x runs on the fp16 MFMA (same dense peak as bf16)
     sims_total, levels = tot["simulations"], tot["levels"]
     out = {
         "value": sims_total / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
         "passes_per_step": passes_per_step, "timed_region_s": dt,
         "config": {"workload": f"{games} concurrent self-play games/GPU x {sims} MCTS sims/move, THREADS_PER_MCTS {threads}, "
-                               f"{a.blocks}-block 256-filter random-init net, {a.dtype}",
+                               f"{a.blocks}-block 256-filter random-init net, {dtype}",
                    "games_per_gpu": games, "sims_per_move": sims, "mcts_threads": threads, "blocks": a.blocks,
                    "step": f"one move for every game = {passes_per_step} passes (tree step + net forward of {games * threads} leaf slots)",
                    "parallelism": f"games sharded x{world}, no data-path collective; 1 all_gather of finished records per iteration"},
@@ -275,14 +279,19 @@ def run_config(ctx, games, sims, threads, steps, warmup, tail):
         "net_evals_per_s": tot["evaluations"] / dt, "mean_depth": levels / max(1, sims_total),
         "games_finished_in_timed_region": tot["games_finished"], "errors": tot["errors"],
         "nodes_dropped": tot["nodes_dropped"], "records_dropped": tot["records_dropped"],
-        "roofline": {"bound": "mfma", "kernel": tower_kernel_name if a.dtype == "bf16" else "fp32 conv chain", "achieved": achieved / 1e12,
+        "dtype": dtype,
+        "roofline": {"bound": "mfma", "kernel": tower_kernel_name, "achieved": achieved / 1e12,
                      "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak,
                      "flop_per_launch": leaves_per_launch * fps, "leaves_per_launch": leaves_per_launch,
                      "leaf_slots_per_launch": games * threads, "avg_launch_ms": prof["net_ms"],
                      "tree_step_avg_ms": prof["tree_ms"], "timed_launches": prof["launches"],
                      # HBM-side bytes per launch from the committed rocprofv3 PMC summary of THIS configuration (null if none)
-                     "traffic": measured_traffic(games, sims, threads, a.blocks, a.dtype)},
+                     "traffic": measured_traffic(games, sims, threads, a.blocks, dtype)},
     }
+    if dtype == "f32x":   # achieved / frac count the ALGORITHMIC flops of an fp32 evaluation; the kernel issues 3 fp16 MFMA passes for them
+        out["roofline"]["note"] = ("fp32-equivalent: `achieved` = algorithmic (valid-tap) flops of ONE evaluation per board / launch time; the kernel "
+                                   "issues 3 x that on the fp16 MFMA, so the matrix pipe's own utilisation is ~3 x `frac` (issued_frac)")
+        out["roofline"]["issued_frac"] = 3 * achieved / peak
     if exchange:
         out["exchange"] = exchange
         out["records_gathered"] = exchange["records_gathered"]
@@ -311,7 +320,8 @@ def main():
     ap.add_argument("--threads", type=int, default=2,
                     help="THREADS_PER_MCTS (-t): search threads per game; 2 is the reference's default (src/settings.h:44)")
     ap.add_argument("--blocks", type=int, default=20)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32x"],
+                    help="bf16 (the benchmarked tower) | f32x (fp32-equivalent fp16-pair MFMA tower) | f32 (fp32 VALU kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip BASELINE configs[1] / configs[2] (N = 1 runs them by default)")
     ap.add_argument("--no-full-games", action="store_true",
@@ -374,6 +384,11 @@ def main():
             k = max(2, (a.steps * (a.sims // a.threads + 1)) // (s // t + 1))
             w = max(1, (a.warmup * (a.sims // a.threads + 1)) // (s // t + 1))
             e = run_config(ctx, g, s, t, k, w, tail=False)
+            e["metric"], e["unit"] = "MCTS simulations/s", "simulations/s"
+            extras.append(e)
+        if a.dtype == "bf16":   # the north-star point again at the reference's precision (it evaluates in fp32, alphazero_nn.cpp:247-248)
+            k = max(2, a.steps // 4)
+            e = run_config(ctx, a.games, a.sims, a.threads, k, max(1, a.warmup // 4), tail=False, dtype="f32x")
             e["metric"], e["unit"] = "MCTS simulations/s", "simulations/s"
             extras.append(e)
     if rank == 0:

@@ -41,8 +41,13 @@ enum {
     AZR_E_STATE = 7             /* call not valid in the engine's current mode */
 };
 
-/* dtype of the policy/value net contractions */
-enum { AZR_NET_F32 = 0, AZR_NET_BF16 = 1 };
+/* arithmetic of the policy/value net contractions.
+ *   AZR_NET_BF16  bf16 operands on the MFMA, fp32 accumulate: the fast path (|d pi|, |d v| <= 2e-2 of an fp32 evaluation)
+ *   AZR_NET_F32   fp32 on the vector ALU: the precise, slow path (tolerance anchor of the tests)
+ *   AZR_NET_F32X  fp32-equivalent on the MFMA: every conv operand as an fp16 pair (22 significand bits), three MFMA passes
+ *                 per layer, fp32 accumulate / epilogue / residual / heads — the reference evaluates in fp32
+ *                 (alphazero_nn.cpp:247-248); <= 2e-5 of the fp32 evaluation.  Conv weights must lie in the fp16 range. */
+enum { AZR_NET_F32 = 0, AZR_NET_BF16 = 1, AZR_NET_F32X = 2 };
 
 /* Mirrors the fields of `class Settings` the hot path reads (src/settings.h:41-64) + engine sizing. */
 typedef struct azr_settings {

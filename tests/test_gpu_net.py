@@ -126,6 +126,74 @@ def test_bf16_tower_at_depth_matches_fp32_oracle(orc, n):
     eng.close()
 
 
+@pytest.mark.parametrize("n,blocks", [(5, 1), (64, 3), (333, 2)])
+def test_f32x_net_matches_oracle_small(orc, n, blocks):
+    """NET_F32X (fp16-pair operands on the MFMA, fp32 everything else; csrc/azr_tower_fx.hip) vs the fp32 oracle: the same
+    tolerance as the fp32 VALU path, |d pi|, |d v| <= 2e-5; odd and ragged batches; batch invariance bit for bit"""
+    P = pkg()
+    base = sample_inputs(64)
+    x = np.concatenate([base] * ((n + 63) // 64))[:n].copy()
+    flat = T.make_net_flat(blocks, seed=3, perturb_bn=True)
+    eng = P.Engine(max(n, 8), blocks=blocks, sims=1, dtype=P.NET_F32X, node_capacity=64)
+    eng.set_weights(flat)
+    pi, v = eng.predict(x)
+    m = min(n, 64)
+    rpi, rv = oracle_forward(orc, flat, blocks, x[:m])
+    dpi, dv = np.abs(pi[:m] - rpi).max(), np.abs(v[:m] - rv).max()
+    print(f"f32x n={n} B={blocks}: max|dpi|={dpi:.2e} max|dv|={dv:.2e}")
+    assert dpi <= 2e-5 and dv <= 2e-5, (dpi, dv)
+    assert np.allclose(pi.sum(1), 1.0, atol=1e-5)
+    for k in range(64, n - 63, 64):   # the same boards in other slots (other workgroups, either board of a workgroup)
+        assert (pi[:64].view(np.uint32) == pi[k:k + 64].view(np.uint32)).all(), k
+        assert (v[:64] == v[k:k + 64]).all(), k
+    for i in range(min(n, 3)):        # one by one == batched (the search relies on it)
+        pa, va = eng.predict(x[i:i + 1])
+        assert (pa[0].view(np.uint32) == pi[i].view(np.uint32)).all() and va[0] == v[i]
+    p3, v3 = eng.predict(x[1:4]) if n >= 4 else (pi[1:4], v[1:4])   # shifted by one slot: the other board of the workgroups
+    assert (p3.view(np.uint32) == pi[1:4].view(np.uint32)).all() and (v3 == v[1:4]).all()
+    eng.close()
+
+
+def test_f32x_tower_at_depth_matches_fp32_oracle(orc):
+    """the gate of the fp32-equivalent path at the bench's depth (B = 20, 41 conv layers): the 128 distinct boards of
+    test_bf16_tower_at_depth_matches_fp32_oracle, first and last workgroups of a 1024-board launch, |d pi|, |d v| <= 2e-5 (the
+    bf16 tower is at 1e-2 on the same boards; tools/f32x_split_study.py predicts 2e-7 from the operand split alone)"""
+    P = pkg()
+    blocks, n = 20, 1024
+    g = np.unique(np.load(os.path.join(T.GOLDEN, "encode.npz"))["in88"], axis=0)
+    pick = g[np.linspace(0, len(g) - 1, 128).astype(int)]
+    head, tail = pick[0::2].copy(), pick[1::2].copy()
+    x = np.concatenate([head] * (n // 64))[:n].copy()
+    x[n - 64:] = tail
+    flat = T.make_net_flat(blocks, seed=3, perturb_bn=True)
+    eng = P.Engine(n, blocks=blocks, sims=1, dtype=P.NET_F32X, node_capacity=64)
+    eng.set_weights(flat)
+    pi, v = eng.predict(x)
+    for name, sl, ref_in in (("first", slice(0, 64), head), ("last", slice(n - 64, n), tail)):
+        rpi, rv = oracle_forward(orc, flat, blocks, ref_in)
+        dpi, dv = np.abs(pi[sl] - rpi).max(), np.abs(v[sl] - rv).max()
+        print(f"f32x B=20 n={n} {name} 64 boards: max|dpi|={dpi:.2e} max|dv|={dv:.2e}")
+        assert dpi <= 2e-5 and dv <= 2e-5, (name, dpi, dv)
+    for k in range(64, n - 127, 64):
+        assert (pi[:64].view(np.uint32) == pi[k:k + 64].view(np.uint32)).all(), k
+        assert (v[:64] == v[k:k + 64]).all(), k
+    eng.close()
+
+
+def test_f32x_refuses_weights_outside_the_fp16_range():
+    P = pkg()
+    flat = T.make_net_flat(1, seed=3)
+    eng = P.Engine(8, blocks=1, sims=1, dtype=P.NET_F32X, node_capacity=64)
+    eng.set_weights(flat)
+    bad = flat.copy()
+    name, off, n = [t for t in T.net_layout(1) if t[0] == "b0a_w"][0]
+    bad[off + 5] = 7.0e4
+    with pytest.raises(P.AzrError) as e:
+        eng.set_weights(bad)
+    assert e.value.code == 1 and "fp16 range" in str(e.value)
+    eng.close()
+
+
 @pytest.mark.parametrize("blocks", [20, 1, 2])
 def test_tile_shapes_agree_bit_for_bit(monkeypatch, blocks):
     """the 4- and 2-boards-per-workgroup single-buffer kernels (azr_tower_sb.hip) and the 1..3-board kernels compute the same
@@ -152,46 +220,96 @@ def test_tile_shapes_agree_bit_for_bit(monkeypatch, blocks):
         assert (out["0"][1].view(np.uint32) == out[mode][1].view(np.uint32)).all(), mode
 
 
-def test_bf16_search_picks_the_fp32_search_moves(orc):
+def oracle_search(orc, flat, blocks, sims, states, seeds, threads=16):
+    """the oracle's own search (oracle/azr_oracle.c, THREADS_PER_MCTS 1) on its own fp32 CPU net for every root: visit counts
+    [n, 43] and the argmax-N move.  One OS thread per root in flight (the C calls release the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    net = T.OrcNet(blocks, flat.ctypes.data_as(T.f32p))
+    cfg = T.default_settings(mcts_simulations=sims, mcts_threads=1)
+    fn = C.cast(orc.orc_net_eval, C.c_void_p)
+    n_out = np.zeros((len(states), 43), np.uint32)
+    mv = np.zeros(len(states), np.uint8)
+
+    def one(i):
+        s, r = T.OrcState(), T.OrcRng()
+        orc.orc_state_unpack(C.byref(s), T.ptr(states[i]))
+        r.x = int(seeds[i])
+        if orc.orc_game_status(C.byref(s), C.byref(cfg)) != -1:
+            return
+        m = orc.orc_mcts_create(C.byref(cfg))
+        assert orc.orc_mcts_simulate(m, C.byref(s), C.byref(r), fn, C.byref(net)) == 0
+        orc.orc_mcts_root_stats(m, C.byref(s), T.ptr(n_out[i]), None, None, None)
+        pi = np.zeros(43, np.float32)
+        orc.orc_mcts_policy(m, C.byref(s), T.ptr(pi))
+        mv[i] = orc.orc_pick_highest(T.ptr(pi))
+        orc.orc_mcts_destroy(m)
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(one, range(len(states))))
+    return n_out.astype(np.int64), mv
+
+
+def test_search_move_agreement_by_net_precision(orc):
     """north_star: "matching reference move selections on seeded boards".  The search is bit-exact GIVEN (pi, v)
-    (test_gpu_mcts.py); this measures what the bf16 net changes: the same 96 seeded golden roots (all phases), B = 20,
-    S = 100, T = 1, searched once on a NET_BF16 engine and once on a NET_F32 engine (the fp32 VALU path, <= 2e-5 of the
-    oracle).  Reported: fraction of roots with the same argmax-N move (AlphaZeroPlayer::takeTurn's pick,
-    alphazero_player.cpp:3-21), the same when the fp32 search's top two visit counts differ by more than 2, and
-    max |dN| / S.  With random-init weights priors are near-uniform, so many roots are decided by one or two visits."""
+    (test_gpu_mcts.py); this measures what the net's arithmetic changes.  The same 96 seeded golden roots (all phases), B = 20,
+    S = 100, T = 1, random-init weights, searched by
+        the oracle on its fp32 CPU net           (the stand-in for the reference's fp32 TensorFlow evaluation)
+        NET_F32   engine (fp32 VALU kernels)
+        NET_F32X  engine (fp16-pair MFMA tower, fp32-equivalent)
+        NET_BF16  engine (the benchmarked tower)
+    Reported per pair: fraction of roots with the same argmax-N move (AlphaZeroPlayer::takeTurn's pick,
+    alphazero_player.cpp:3-21), the same on the roots whose reference top-two visit counts differ by more than 2, max |dN| / S
+    and the mean total-variation distance of the visit distributions.  NET_F32 vs oracle is the NOISE FLOOR: two fp32
+    evaluations that differ by summation order only (<= 2e-5) — with random-init weights priors are near-uniform and a root can
+    be decided by the sign of a 1e-6 value difference."""
     P = pkg()
     blocks, sims = 20, 100
     gold = np.load(os.path.join(T.GOLDEN, "rules_games.npz"))
     states = gold["states"][::29][:96]
     G = len(states)
     flat = T.make_net_flat(blocks, seed=20260002)
+    seeds = np.arange(500, 500 + G, dtype=np.uint32)
     out = {}
-    for name, dt in (("bf16", P.NET_BF16), ("f32", P.NET_F32)):
+    for name, dt in (("bf16", P.NET_BF16), ("f32x", P.NET_F32X), ("f32", P.NET_F32)):
         eng = P.Engine(G, blocks=blocks, sims=sims, dtype=dt, threads=1)
         eng.set_weights(flat)
         eng.set_states(states)
-        eng.set_rng(np.arange(500, 500 + G, dtype=np.uint32))
+        eng.set_rng(seeds)
         st = eng.status()
         eng.simulate()
         n_, _, _ = eng.root_stats()
-        out[name] = (n_.astype(np.int64), eng.pick(sample=False), st)
+        out[name] = (n_.astype(np.int64), eng.pick(sample=False))
         eng.close()
-    (nb, mb, st), (nf, mf, _) = out["bf16"], out["f32"]
     live = st == -1
     assert live.sum() >= 80
-    nb, nf, mb, mf = nb[live], nf[live], mb[live], mf[live]
-    assert (nb.sum(1) == sims).all() and (nf.sum(1) == sims).all()
-    same = mb == mf
-    top2 = np.sort(nf, axis=1)[:, -2:]
-    clear = (top2[:, 1] - top2[:, 0]) > 2
-    dn = np.abs(nb - nf).max() / sims
-    l1 = (np.abs(nb - nf).sum(1) / (2.0 * sims)).mean()
-    print(f"bf16-vs-fp32 search, B=20 S=100 T=1, {live.sum()} roots: identical argmax-N {same.mean():.3f}; "
-          f"on the {clear.sum()} roots whose fp32 top-2 margin > 2 visits: {same[clear].mean():.3f}; "
-          f"max|dN|/S = {dn:.3f}; mean total-variation distance of the visit distributions = {l1:.4f}")
-    # measured on MI355X (round 2): 0.958 identical over the 96 roots, 0.912 on the 34 clear ones, mean TV 0.018
-    assert same.mean() >= 0.88 and same[clear].mean() >= 0.80, (same.mean(), same[clear].mean())
-    assert l1 <= 0.06, l1
+    out["oracle"] = oracle_search(orc, flat, blocks, sims, states, seeds)
+
+    def compare(a, b):   # b = the reference side
+        (na, ma), (nb, mb) = out[a], out[b]
+        na, nb, ma, mb = na[live], nb[live], ma[live], mb[live]
+        assert (na.sum(1) == sims).all() and (nb.sum(1) == sims).all(), (a, b)
+        same = ma == mb
+        top2 = np.sort(nb, axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 2
+        dn = np.abs(na - nb).max() / sims
+        tv = (np.abs(na - nb).sum(1) / (2.0 * sims)).mean()
+        ident = (na == nb).all(1).mean()
+        print(f"{a:5s} vs {b:6s}: identical argmax-N {same.mean():.3f} ({same.sum()}/{len(same)}); on the {clear.sum()} clear roots "
+              f"{same[clear].mean():.3f}; identical visit vectors {ident:.3f}; max|dN|/S {dn:.2f}; mean TV distance {tv:.4f}")
+        return same.mean(), same[clear].mean(), tv
+
+    print(f"search move agreement, B=20 S=100 T=1, {live.sum()} live roots:")
+    floor = compare("f32", "oracle")
+    fx_o = compare("f32x", "oracle")
+    fx_f = compare("f32x", "f32")
+    bf_o = compare("bf16", "oracle")
+    bf_f = compare("bf16", "f32")
+    # the benchmarked bf16 tower (measured on MI355X, round 2: 0.958 identical vs NET_F32 over the 96 roots, 0.912 on the clear ones)
+    assert bf_f[0] >= 0.88 and bf_f[1] >= 0.80 and bf_f[2] <= 0.06, bf_f
+    # the fp32-equivalent tower is as close to the oracle's search as the fp32 VALU kernels are (the noise floor), and far
+    # closer than bf16
+    assert fx_o[0] >= floor[0] - 0.03 and fx_o[2] <= floor[2] + 0.01, (fx_o, floor)
+    assert fx_f[2] <= bf_f[2], (fx_f, bf_f)
 
 
 def test_selfplay_bf16_runs_clean():
