@@ -66,7 +66,7 @@ EXPORTS = [
     "azr_engine_valid_moves", "azr_engine_make_moves", "azr_engine_status", "azr_engine_encode",
     "azr_nn_param_count", "azr_nn_init_random", "azr_nn_set_weights", "azr_nn_get_weights", "azr_nn_load", "azr_nn_save",
     "azr_nn_predict", "azr_nn_train", "azr_nn_train_dp", "azr_nn_train_batch", "azr_nn_train_grads", "azr_nn_train_reset", "azr_mcts_clear", "azr_mcts_trim", "azr_mcts_simulate", "azr_mcts_begin", "azr_mcts_leaves",
-    "azr_mcts_apply", "azr_mcts_root_stats", "azr_mcts_policy", "azr_mcts_pick", "azr_selfplay_start", "azr_selfplay_start_games",
+    "azr_mcts_apply", "azr_mcts_root_stats", "azr_mcts_policy", "azr_mcts_pick", "azr_selfplay_start", "azr_selfplay_start_games", "azr_selfplay_start_from_states",
     "azr_selfplay_run", "azr_selfplay_counters", "azr_samples_drain", "azr_samples_device_view", "azr_samples_copy_device", "azr_profile_last_run",
     "azr_device_synchronize", "azr_debug_tower_clock", "azr_debug_tower_trace", "azr_debug_tower_plan", "azr_arena_start", "azr_arena_run", "azr_arena_results", "azr_arena_log",
     "azr_arena_set_opponent_net", "azr_arena_collect_samples",
@@ -105,6 +105,7 @@ def load_library():
         L.azr_nn_train_reset.argtypes = [C.c_void_p]
         L.azr_selfplay_start.argtypes = [C.c_void_p, C.c_uint32]
         L.azr_selfplay_start_games.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+        L.azr_selfplay_start_from_states.argtypes = [C.c_void_p, C.c_uint32]
         L.azr_samples_copy_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.azr_selfplay_run.argtypes = [C.c_void_p, C.c_int]
         L.azr_samples_drain.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -358,6 +359,10 @@ class Engine:
     def selfplay_start_games(self, base_seed, games):
         """exactly `games` games (seeds base_seed .. base_seed + games - 1), each played to its end"""
         self._chk(self.L.azr_selfplay_start_games(self.h, base_seed, games))
+
+    def selfplay_start_from_states(self, base_seed=20260001):
+        """self-play goes on from the states / RNG streams set with set_states / set_rng"""
+        self._chk(self.L.azr_selfplay_start_from_states(self.h, base_seed))
 
     def selfplay_run(self, passes):
         self._chk(self.L.azr_selfplay_run(self.h, passes))

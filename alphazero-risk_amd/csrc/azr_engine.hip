@@ -800,7 +800,8 @@ __global__ __launch_bounds__(64) void k_pick(Dev E, int sample, uint8_t* moves)
     }
 }
 
-__global__ __launch_bounds__(64) void k_selfplay_start(Dev E)
+// keep != 0: the games go on from the states and RNG streams the caller has set (azr_selfplay_start_from_states)
+__global__ __launch_bounds__(64) void k_selfplay_start(Dev E, int keep)
 {
     const int g = blockIdx.x;
     Ctl c;
@@ -813,12 +814,14 @@ __global__ __launch_bounds__(64) void k_selfplay_start(Dev E)
     c.game_no = 0; c.nsamples = 0; c.decisions = 0; c.status = ST_NOT_ENDED;
     c.seed = E.base_seed + (uint32_t)g;
     if (E.sp_quota && (unsigned long long)g >= E.sp_quota) c.mode = 0;  // fewer games asked for than slots
-    WS s;
-    ws_blank(s);
-    s.rng = rng_seed(c.seed);
-    new_game(s);
-    c.rng = s.rng;
-    ws_store(s, E.state + (size_t)g * GREC);
+    if (!keep) {
+        WS s;
+        ws_blank(s);
+        s.rng = rng_seed(c.seed);
+        new_game(s);
+        c.rng = s.rng;
+        ws_store(s, E.state + (size_t)g * GREC);
+    }
     ctl_store(c, &E.ctl[g]);
 }
 
@@ -1254,7 +1257,7 @@ extern "C" int azr_mcts_pick(azr_engine* h, int sample, uint8_t* moves)
 }
 
 // ---- device-resident self-play ------------------------------------------------------------------------
-static int selfplay_start(azr_engine* h, uint32_t base_seed, unsigned long long quota)
+static int selfplay_start(azr_engine* h, uint32_t base_seed, unsigned long long quota, int keep = 0)
 {
     h->d.base_seed = base_seed;
     h->d.sp_quota = quota;
@@ -1265,9 +1268,15 @@ static int selfplay_start(azr_engine* h, uint32_t base_seed, unsigned long long 
     HIPCHK(h, hipMemcpyAsync(h->d.sp_started, &started, sizeof started, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d.counters, 0, (size_t)h->d.G * sizeof(Counters), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d.ring_count, 0, sizeof(unsigned long long), h->stream));
-    LAUNCH(h, k_selfplay_start, h->d);
+    LAUNCH(h, k_selfplay_start, h->d, keep);
     SYNC(h);
     return AZR_OK;
+}
+
+extern "C" int azr_selfplay_start_from_states(azr_engine* h, uint32_t base_seed)
+{
+    ENTER(h);
+    return selfplay_start(h, base_seed, 0, 1);
 }
 
 extern "C" int azr_selfplay_start(azr_engine* h, uint32_t base_seed)

@@ -153,7 +153,46 @@ def spawn_ranks(a, argv):
         raise SystemExit("bench.py: rank 0 did not report n_gpus == --gpus")
 
 
-def run_config(ctx, games, sims, threads, steps, warmup, tail, dtype=None):
+def midgame_states(games, rank):
+    """`games` running positions from the committed golden games (tests/golden/rules_games.npz: 20 seeded games of the REAL
+    reference played with random legal moves, every phase and every stage of a game), evenly spread, with an RNG stream each"""
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "rules_games.npz"))
+    st = g["states"]
+    ends = set(int(x) - 1 for x in g["starts"][1:])            # the last recorded state of a game precedes its final move
+    live = np.array([i for i in range(len(st)) if i not in ends])
+    idx = live[(np.arange(games) * len(live)) // games]
+    phases = np.bincount(st[idx, 149], minlength=6).tolist()   # Data::roundPhase (state/state.h:86-105)
+    seeds = (np.arange(games, dtype=np.uint64) * 7919 + 104729 * (rank + 1) + 1) % 2147483646 + 1
+    return st[idx].copy(), seeds.astype(np.uint32), phases
+
+
+def config0_play(blocks):
+    """BASELINE configs[0], `-m play --mcts=16 --cg=100` (AlphaZero vs ScriptPlayer), at its stated size through the C++
+    host CLI above the C-ABI: wall time of the whole process (engine creation, random-init checkpoint, 100 games)"""
+    host = os.path.join(ROOT, "alphazero-risk_amd", "host")
+    exe = os.path.join(host, "AlphaZero_Risk_hip")
+    try:
+        if not os.path.exists(exe):
+            subprocess.check_call(["make", "-s", "-C", host], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            cmd = [exe, "-m", "play", "--mcts=16", "--cg=100", f"--blocks={blocks}"]
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=900)
+            dt = time.perf_counter() - t0
+        tail = r.stdout.strip().split("\n")[-4:]
+        if r.returncode != 0 or not tail or tail[0] != "Games: 100":
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        d_, p1, p2 = (int(t.split(":")[1]) for t in tail[1:])
+        return {"command": "AlphaZero_Risk_hip " + " ".join(cmd[1:]), "wall_s": dt, "games": 100, "draws": d_, "alphazero_wins": p1,
+                "script_wins": p2, "games_per_s": 100 / dt,
+                "note": "random-init net; the reference's own CPU run of this command with its _DEBUG random-NN fake took 3.4 s (BASELINE.md §2)"}
+    except Exception as e:   # noqa: BLE001  (a missing compiler on the box must not cost the headline)
+        return {"error": repr(e)[-300:]}
+
+
+def run_config(ctx, games, sims, threads, steps, warmup, tail, dtype=None, midgame=False):
     """K steps of one configuration on this rank's GPU; returns the per-rank measurements (reduced by the caller)"""
     a, pkg, shard, torch, dist = ctx["a"], ctx["pkg"], ctx["shard"], ctx["torch"], ctx["dist"]
     dtype = dtype or a.dtype
@@ -163,7 +202,14 @@ def run_config(ctx, games, sims, threads, steps, warmup, tail, dtype=None):
     eng = pkg.Engine(games, blocks=a.blocks, sims=sims, dtype={"bf16": pkg.NET_BF16, "f32": pkg.NET_F32, "f32x": pkg.NET_F32X}[dtype],
                      device=local, threads=threads)
     eng.init_random(20260002)
-    eng.selfplay_start(shard.rank_base_seed(20260001, rank))
+    phases = None
+    if midgame:   # the move loop entered in the middle of games: every phase, every stage of a game from the first pass on
+        st, seeds, phases = midgame_states(games, rank)
+        eng.set_states(st)
+        eng.set_rng(seeds)
+        eng.selfplay_start_from_states(shard.rank_base_seed(20260001, rank))
+    else:
+        eng.selfplay_start(shard.rank_base_seed(20260001, rank))
     tower_kernel_name = "fp32 conv chain"
     if dtype == "f32x":
         tower_kernel_name = (f"k_tower_fx<2> x {(games * threads + 1) // 2} workgroups of 2 boards (one whole net forward at fp32-equivalent precision: "
@@ -271,11 +317,13 @@ def run_config(ctx, games, sims, threads, steps, warmup, tail, dtype=None):
         "config": {"workload": f"{games} concurrent self-play games/GPU x {sims} MCTS sims/move, THREADS_PER_MCTS {threads}, "
                                f"{a.blocks}-block 256-filter random-init net, {dtype}",
                    "games_per_gpu": games, "sims_per_move": sims, "mcts_threads": threads, "blocks": a.blocks,
-                   "step": f"one move for every game = {passes_per_step} passes (tree step + net forward of {games * threads} leaf slots)",
+                   "step": f"{passes_per_step} passes (pass = tree step + net forward of the {games * threads} leaf slots) = one decision of every "
+                           f"game whose root has to be expanded first; a root that survived the trim needs {sims // threads} (see decisions_per_game_and_step)",
                    "parallelism": f"games sharded x{world}, no data-path collective; 1 all_gather of finished records per iteration"},
         "simulations_per_s_p50_rank0": sorted(chunk_rates)[len(chunk_rates) // 2] if chunk_rates else None,
         "self_play_games_per_s": games_rate["games_per_s"] if games_rate else None,
         "self_play_games_window": games_rate, "decisions_per_s": tot["decisions"] / dt,
+        "decisions_per_game_and_step": tot["decisions"] / max(1, steps * games * world),
         "net_evals_per_s": tot["evaluations"] / dt, "mean_depth": levels / max(1, sims_total),
         "games_finished_in_timed_region": tot["games_finished"], "errors": tot["errors"],
         "nodes_dropped": tot["nodes_dropped"], "records_dropped": tot["records_dropped"],
@@ -292,6 +340,9 @@ def run_config(ctx, games, sims, threads, steps, warmup, tail, dtype=None):
         out["roofline"]["note"] = ("fp32-equivalent: `achieved` = algorithmic (valid-tap) flops of ONE evaluation per board / launch time; the kernel "
                                    "issues 3 x that on the fp16 MFMA, so the matrix pipe's own utilisation is ~3 x `frac` (issued_frac)")
         out["roofline"]["issued_frac"] = 3 * achieved / peak
+    if midgame:
+        out["start"] = {"from": "tests/golden/rules_games.npz (positions of 20 seeded reference games, random legal moves)",
+                        "positions_by_phase": dict(zip(["SETUP", "SETUP_NEUTRAL", "REINFORCEMENT", "ATTACK", "ATTACK_MOBILIZATION", "FORTIFY"], phases))}
     if exchange:
         out["exchange"] = exchange
         out["records_gathered"] = exchange["records_gathered"]
@@ -375,7 +426,7 @@ def main():
     ctx = dict(a=a, pkg=pkg, shard=shard, torch=torch, dist=dist, rank=rank, world=world, local=local, dev=dev, cdev=cdev,
                backend=backend, use_dist=use_dist)
     head = run_config(ctx, a.games, a.sims, a.threads, a.steps, a.warmup, tail=not a.no_full_games)
-    extras = []
+    extras, mid = [], None
     if world == 1 and not a.no_extra:
         for g, s, t in EXTRA_CONFIGS:
             if (g, s, t) == (a.games, a.sims, a.threads):
@@ -386,6 +437,10 @@ def main():
             e = run_config(ctx, g, s, t, k, w, tail=False)
             e["metric"], e["unit"] = "MCTS simulations/s", "simulations/s"
             extras.append(e)
+        # the headline configuration entered in the MIDDLE of games (all phases, deep trees) instead of after the deal
+        e = run_config(ctx, a.games, a.sims, a.threads, a.steps, a.warmup, tail=False, midgame=True)
+        e["metric"], e["unit"] = "MCTS simulations/s", "simulations/s"
+        mid = e
         if a.dtype == "bf16":   # the north-star point again at the reference's precision (it evaluates in fp32, alphazero_nn.cpp:247-248)
             k = max(2, a.steps // 4)
             e = run_config(ctx, a.games, a.sims, a.threads, k, max(1, a.warmup // 4), tail=False, dtype="f32x")
@@ -398,8 +453,13 @@ def main():
         out.update(head)
         if extras:
             out["extra_configs"] = extras
+        if mid is not None:
+            out["midgame_leg"] = mid
+            out["midgame_leg"]["vs_headline"] = mid["value"] / out["value"]
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.blocks, a.sims, a.threads)
+        if world == 1 and not a.no_extra:
+            out["config0_play"] = config0_play(a.blocks)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -168,6 +168,10 @@ int azr_selfplay_start(azr_engine* h, uint32_t base_seed);
  * `games` games — seeds base_seed .. base_seed + games - 1, handed to whichever slot is free next — and play every one
  * of them to its end; slots idle once no game is left to start.  Done when games_finished + errors == games. */
 int azr_selfplay_start_games(azr_engine* h, uint32_t base_seed, uint64_t games);
+/* The move loop entered in the MIDDLE of games: game g goes on from the state and RNG stream the caller has set
+ * (azr_engine_set_states / azr_engine_set_rng; states must be running games), its records start there; a finished game's
+ * slot restarts as under azr_selfplay_start (seeds base_seed + G + g, base_seed + 2G + g, ...). */
+int azr_selfplay_start_from_states(azr_engine* h, uint32_t base_seed);
 /* Run `passes` passes of the hot path: every pass = one tree step (backup/expand + select to the next leaf,
  * decisions, moves, game restarts — all on device) + one batched net evaluation of the G leaves. */
 int azr_selfplay_run(azr_engine* h, int passes);

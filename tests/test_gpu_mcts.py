@@ -161,3 +161,68 @@ def test_full_selfplay_games_device_resident_vs_oracle(orc, threads):
     for g in range(G):
         assert want[g].tobytes() in blob, f"game {g} record stream not found in the device's output"
     eng.close()
+
+
+def test_selfplay_from_midgame_states_vs_oracle(orc):
+    """azr_selfplay_start_from_states: the trainer's move loop entered in the MIDDLE of games (bench.py's second timed leg).
+    12 golden positions of all phases, their own RNG streams; the device plays every game to its end and must produce the
+    record stream of the oracle's loop (search, temperature pick, record, move — orc_selfplay_game's body) started from the
+    same position with the same stream, the DEVICE net called back for every evaluation."""
+    P = pkg()
+    sims, B = 6, 1
+    gold = np.load(os.path.join(T.GOLDEN, "rules_games.npz"))
+    states = gold["states"][::471][:12].copy()
+    G = len(states)
+    assert len(set(states[:, 149])) >= 4   # several phases
+    seeds = np.arange(7000, 7000 + G, dtype=np.uint32)
+    eng = P.Engine(G, blocks=B, sims=sims, dtype=P.NET_F32, threads=1)
+    flat = T.make_net_flat(B, seed=11, perturb_bn=True)
+    eng.set_weights(flat)
+    eng.set_states(states)
+    eng.set_rng(seeds)
+    eng.selfplay_start_from_states(31337)
+    for _ in range(400):
+        eng.selfplay_run(64)
+        if eng.counters()["games_finished"] >= 3 * G:   # every slot's FIRST game (the continued one) is over long before
+            break
+    c = eng.counters()
+    assert c["errors"] == 0 and c["nodes_dropped"] == 0 and c["records_dropped"] == 0
+    blob = eng.drain().tobytes()
+
+    @T.EVAL_FN
+    def hip_eval(ctx, in88, pi, v):
+        x = np.ctypeslib.as_array(in88, shape=(88,)).copy()[None]
+        p, vv = eng.predict(x)
+        C.memmove(pi, p.ctypes.data, 43 * 4)
+        v[0] = float(vv[0])
+
+    cfg = T.default_settings(mcts_simulations=sims, mcts_threads=1)
+    for g in range(G):
+        s, r = T.OrcState(), T.OrcRng()
+        orc.orc_state_unpack(C.byref(s), T.ptr(states[g]))
+        r.x = int(seeds[g])
+        m = orc.orc_mcts_create(C.byref(cfg))
+        recs, players = [], []
+        gs = orc.orc_game_status(C.byref(s), C.byref(cfg))
+        assert gs == -1
+        while gs == -1:
+            assert orc.orc_mcts_simulate(m, C.byref(s), C.byref(r), hip_eval, None) == 0
+            pi = np.zeros(43, np.float32)
+            assert orc.orc_mcts_policy(m, C.byref(s), T.ptr(pi)) == 0
+            mv = orc.orc_pick_highest(T.ptr(pi)) if s.round > cfg.temperature_threshold else orc.orc_pick_random(T.ptr(pi), C.byref(r))
+            rec = np.zeros(265, np.uint8)
+            rec[0] = np.uint8(s.cur)
+            orc.orc_encode(C.byref(s), T.ptr(rec[1:89]))
+            rec[93:265] = pi.view(np.uint8)
+            recs.append(rec)
+            players.append(s.cur)
+            assert orc.orc_make_move(C.byref(s), mv, C.byref(r), C.byref(cfg)) == 0
+            gs = orc.orc_game_status(C.byref(s), C.byref(cfg))
+        orc.orc_mcts_destroy(m)
+        z = np.zeros(len(recs), np.float32)
+        orc.orc_update_values(T.ptr(np.array(players, np.int8)), len(recs), gs, T.ptr(z))
+        for i, rec in enumerate(recs):
+            rec[89:93] = z[i:i + 1].view(np.uint8)
+        want = np.stack(recs).tobytes()
+        assert want in blob, f"slot {g}: the continued game's record stream was not found in the device's output"
+    eng.close()
