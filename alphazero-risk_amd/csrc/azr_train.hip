@@ -246,6 +246,21 @@ __device__ __forceinline__ void split_store4(const float (&v)[4], size_t i4, uin
     if (p2) reinterpret_cast<uint2*>(p2)[i4] = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
 }
 
+// the fp16 pair of 4 consecutive values: hi = rne16(v), lo = rne16(v - hi) (unscaled: the matrix core takes fp16 subnormals),
+// 22 significand bits — the operand format of the 3-pass forward conv (t_conv_rs<1, 2, 0, true>)
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ void split_store4_f16(const float (&v)[4], size_t i4, uint16_t* q0, uint16_t* q1)
+{
+    _Float16 h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        h[j] = (_Float16)v[j];
+        l[j] = (_Float16)(v[j] - (float)h[j]);
+    }
+    reinterpret_cast<uint2*>(q0)[i4] = make_uint2(__builtin_bit_cast(uint32_t, f16x2_t{h[0], h[1]}), __builtin_bit_cast(uint32_t, f16x2_t{h[2], h[3]}));
+    reinterpret_cast<uint2*>(q1)[i4] = make_uint2(__builtin_bit_cast(uint32_t, f16x2_t{l[0], l[1]}), __builtin_bit_cast(uint32_t, f16x2_t{l[2], l[3]}));
+}
+
 // x[n] fp32 -> NP bf16 part arrays (n % 4 == 0)
 template <int NP>
 __global__ __launch_bounds__(256) void t_split(const float* __restrict__ x, size_t n4, uint16_t* __restrict__ p0, uint16_t* __restrict__ p1,
@@ -426,9 +441,10 @@ __global__ __launch_bounds__(256) void t_gemm_sb(Parts A, int lda, Parts B, int 
 // =====================================================================================================================
 constexpr size_t WPACK = (size_t)KC * NF;  // elements per layer, part and view
 
+// wscale > 0: fp16 PAIRS of wscale * W instead of bf16 parts (p0 = hi, p1 = lo; the forward conv on the fp16 MFMA)
 template <int NP>
 __global__ __launch_bounds__(256) void t_pack_w(const float* __restrict__ flat, int view, uint16_t* __restrict__ p0, uint16_t* __restrict__ p1,
-                                                uint16_t* __restrict__ p2)
+                                                uint16_t* __restrict__ p2, float wscale = 0.0f)
 {
     // one thread = one lane's 8 values of one fragment: index = ((kt * 16 + nt) * 64 + lane)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -442,6 +458,14 @@ __global__ __launch_bounds__(256) void t_pack_w(const float* __restrict__ flat, 
     for (int j = 0; j < 8; j++) {
         const float v = view == 0 ? W[((size_t)tap * NF + (c0 + j)) * NF + n]    // ci = c0 + j, co = n
                                   : W[((size_t)tap * NF + n) * NF + (c0 + j)];   // ci = n, co = c0 + j
+        if (wscale > 0.0f) {
+            const float vs = v * wscale;
+            const _Float16 hh = (_Float16)vs, ll = (_Float16)(vs - (float)hh);
+            h[j] = __builtin_bit_cast(uint16_t, hh);
+            m[j] = __builtin_bit_cast(uint16_t, ll);
+            lo[j] = 0u;
+            continue;
+        }
         h[j] = bf_rne_bits(v);
         const float r1 = v - __uint_as_float(h[j] << 16);
         m[j] = bf_rne_bits(r1);
@@ -561,7 +585,8 @@ struct Rs {
 };
 
 // one k-step (one tap of one 32-channel slice) of t_conv_rs; everything that depends on the tap is a compile-time constant
-template <int AMODE, int NP, int TAP>
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+template <int AMODE, int NP, int TAP, bool F16 = false>
 __device__ __forceinline__ void rs_tap(const uint8_t* bufc, int kc, const __amdgpu_buffer_rsrc_t (&wsrc)[NP], uint32_t loff,
                                        const uint32_t (&arow)[9][Rs::MT], u32x4 (&bq)[Rs::RING][NP][Rs::NT], f32x4 (&acc)[Rs::MT][Rs::NT],
                                        s16x8 (&a)[Rs::MT][NP])
@@ -583,9 +608,14 @@ __device__ __forceinline__ void rs_tap(const uint8_t* bufc, int kc, const __amdg
             for (int p = 0; p < NPASS; p++) {
                 const int qa = RsPass<NP>::QA[p], qb = RsPass<NP>::QB[p];
 #pragma unroll
-                for (int nt = 0; nt < NT; nt++)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[cur][qb][nt]),
-                                                                            __builtin_bit_cast(bf16x8, a[mt][qa]), acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; nt++) {
+                    if constexpr (F16)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, bq[cur][qb][nt]),
+                                                                               __builtin_bit_cast(f16x8_t, a[mt][qa]), acc[mt][nt], 0, 0, 0);
+                    else
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[cur][qb][nt]),
+                                                                                __builtin_bit_cast(bf16x8, a[mt][qa]), acc[mt][nt], 0, 0, 0);
+                }
                 // one refill load of the ring slot the previous k-step freed, dealt out over the k-step
                 const int s2 = j * NPASS + p;
 #pragma unroll
@@ -609,8 +639,49 @@ __device__ __forceinline__ void rs_tap(const uint8_t* bufc, int kc, const __amdg
         }
 }
 
-template <int AMODE, int NP>
-__global__ __launch_bounds__(256, 1) void t_conv_rs(Parts A, Parts Bp, float* __restrict__ C, int boards)
+// What the backward-data conv of layer l can do for layer l - 1 on its way out (FUSE = 1): its output rows are layer l - 1's
+// dOut, still in registers — the shortcut gradient joins them here (first conv of a block: + DS, the job of t_add), and
+// stage 1 of layer l - 1's batch-norm backward (t_bn_bwd_stats: per channel sum of dz and of dz * xhat, dz = dOut where the
+// post-activation is positive) is taken per block of 2 boards, in double, in a fixed order: cells of a lane, then the 16
+// lanes of a channel group.  part[blockIdx][2][256] is what t_bn_bwd_finalize / t_parts_sum read (R = number of blocks).
+struct BwdFuse {
+    const float* DS;      // shortcut gradient to add to the output rows, or null
+    const float* Apost;   // layer l - 1: post-activation, pre-BN conv output, batch mean / 1 / std per channel
+    const float* Y;
+    const float* mean;
+    const float* istd;
+    double* part;
+};
+
+// What the conv can do on the way IN (PRO): its A operand is an elementwise function of tensors that are complete once the
+// batch statistics are — so instead of a kernel that writes the operand parts and this one reading them back, the staging path
+// computes them (each block stages every element of its 2 boards exactly once) and writes what later kernels still need:
+//   PRO = 1 (forward conv of layer l): A_{l-1} = relu(gamma (Y_{l-1} - mean) istd + beta (+ S)) — t_bn_apply's arithmetic — goes
+//            to LDS as fp16 pair; side outputs: A_{l-1} in fp32 (backward masks, shortcut, heads) and its bf16 hi / mid parts (the
+//            weight-gradient GEMM's operand);
+//   PRO = 2 (backward-data conv of layer l): dY_l = gamma istd (dz - sum(dz)/n - xhat sum(dz xhat)/n), dz = dOut where the
+//            post-activation is positive — t_bn_bwd_apply's arithmetic — goes to LDS as bf16 hi / mid; side outputs: those two parts
+//            (the weight-gradient GEMM, launched AFTER this kernel) and dz itself where the layer closes a block (the shortcut
+//            gradient DS).
+struct ProFuse {
+    const float* X;       // PRO 1: Y_{l-1}   | PRO 2: dOut_l
+    const float* S;       // PRO 1: shortcut input or null | PRO 2: Apost_l
+    const float* Y;       // PRO 2: Y_l
+    const float* mean;    // per channel [256]
+    const float* istd;
+    const float* bn;      // gamma | beta
+    const float* sums;    // PRO 2: [2][256] sum(dz), sum(dz xhat)
+    float inv_count;      // PRO 2
+    float* O;             // PRO 1: A_{l-1} (fp32) | PRO 2: dz (DS) or null
+    uint16_t* p0;         // bf16 hi / mid parts of the computed operand
+    uint16_t* p1;
+};
+
+// F16: the operands are fp16 pairs (NP = 2: hi, lo) on v_mfma_f32_16x16x32_f16 and the sums are multiplied by `oscale` on the way
+// out (the packed kernel carries a power-of-two scale) — the forward conv in 3 passes instead of the 6 of three bf16 parts.
+template <int AMODE, int NP, int FUSE = 0, bool F16 = false, int PRO = 0>
+__global__ __launch_bounds__(256, 1) void t_conv_rs(Parts A, Parts Bp, float* __restrict__ C, int boards, BwdFuse F = BwdFuse{}, float oscale = 1.0f,
+                                                    ProFuse Pf = ProFuse{})
 {
     constexpr int NB = Rs::NB, ROWS = Rs::ROWS, MT = Rs::MT, ZR = Rs::ZR, NT = Rs::NT, RING = Rs::RING, CHB = Rs::CHB, PB = Rs::PB;
     constexpr int UN = (NP * ROWS * 4 + 255) / 256;   // 16-byte units of a slice per thread
@@ -658,33 +729,121 @@ __global__ __launch_bounds__(256, 1) void t_conv_rs(Parts A, Parts Bp, float* __
         }
         taprow[i] = (uint8_t)src;
     }
-    // this thread's units of a slice: (part, cell, 16-byte segment) -> global element offset (chunk 0) and LDS byte offset
-    size_t goff[UN];
-    uint32_t loffs[UN];
-    bool uok[UN];
-#pragma unroll
-    for (int i = 0; i < UN; i++) {
-        const int u = tid + 256 * i, q = u / (ROWS * 4), rem = u - q * (ROWS * 4), cell = rem >> 2, seg = rem & 3;
-        uok[i] = u < NP * ROWS * 4 && cell < nbv * NPOS;
-        goff[i] = (size_t)(m0 + cell) * NF + seg * 8;
-        loffs[i] = (uint32_t)((u < NP * ROWS * 4 ? q : 0) * PB + (u < NP * ROWS * 4 ? rowof[cell] : 0) * CHB + seg * 16);
-    }
-    auto fetch = [&](int kc, uint4 (&r)[UN]) {
+    // this thread's units of a slice.  PRO = 0: (part, cell, 16-byte segment of 8 halfs) -> global element offset (chunk 0) and LDS
+    // byte offset.  PRO != 0: (cell, 4 channels): the fp32 sources are fetched, the operand is computed when the slice is stashed.
+    constexpr int UNR = PRO ? (ROWS * 8 + 255) / 256 : UN;
+    size_t goff[UNR];
+    uint32_t loffs[UNR];
+    bool uok[UNR];
+    __shared__ __attribute__((aligned(16))) float ptab[PRO ? 5 * NF : 4];   // PRO: per-channel parameters of the elementwise function
+    if constexpr (PRO == 0) {
 #pragma unroll
         for (int i = 0; i < UN; i++) {
-            const int q = (tid + 256 * i) / (ROWS * 4);
-            r[i] = uok[i] ? *reinterpret_cast<const uint4*>(A.p[q < NP ? q : 0] + goff[i] + kc * 32) : make_uint4(0u, 0u, 0u, 0u);
+            const int u = tid + 256 * i, q = u / (ROWS * 4), rem = u - q * (ROWS * 4), cell = rem >> 2, seg = rem & 3;
+            uok[i] = u < NP * ROWS * 4 && cell < nbv * NPOS;
+            goff[i] = (size_t)(m0 + cell) * NF + seg * 8;
+            loffs[i] = (uint32_t)((u < NP * ROWS * 4 ? q : 0) * PB + (u < NP * ROWS * 4 ? rowof[cell] : 0) * CHB + seg * 16);
+        }
+    } else {
+        static_assert(NP == 2, "the computed operand has two parts");
+#pragma unroll
+        for (int i = 0; i < UNR; i++) {
+            const int u = tid + 256 * i, cell = u >> 3, seg = u & 7;
+            uok[i] = u < ROWS * 8 && cell < nbv * NPOS;
+            goff[i] = (size_t)(m0 + cell) * NF + seg * 4;
+            loffs[i] = (uint32_t)((u < ROWS * 8 ? rowof[cell] : 0) * CHB + seg * 8);
+        }
+        for (int i = tid; i < NF; i += 256) {
+            ptab[i] = Pf.bn[i];                                  // gamma
+            ptab[2 * NF + i] = Pf.mean[i];
+            ptab[3 * NF + i] = Pf.istd[i];
+            if constexpr (PRO == 1) ptab[NF + i] = Pf.bn[NF + i];   // beta
+            else { ptab[NF + i] = Pf.sums[i] * Pf.inv_count; ptab[4 * NF + i] = Pf.sums[NF + i] * Pf.inv_count; }
+        }
+        __syncthreads();
+    }
+    struct Raw { uint4 a, b, c; };   // PRO = 0: a = 16 bytes of a part.  PRO 1: a = Y, b = S.  PRO 2: a = dOut, b = Apost, c = Y
+    auto fetch = [&](int kc, Raw (&r)[UNR]) {
+#pragma unroll
+        for (int i = 0; i < UNR; i++) {
+            if constexpr (PRO == 0) {
+                const int q = (tid + 256 * i) / (ROWS * 4);
+                r[i].a = uok[i] ? *reinterpret_cast<const uint4*>(A.p[q < NP ? q : 0] + goff[i] + kc * 32) : make_uint4(0u, 0u, 0u, 0u);
+            } else {
+                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+                r[i].a = uok[i] ? *reinterpret_cast<const uint4*>(Pf.X + goff[i] + kc * 32) : z;
+                r[i].b = (uok[i] && Pf.S) ? *reinterpret_cast<const uint4*>(Pf.S + goff[i] + kc * 32) : z;
+                if constexpr (PRO == 2) r[i].c = uok[i] ? *reinterpret_cast<const uint4*>(Pf.Y + goff[i] + kc * 32) : z;
+            }
         }
     };
-    auto stash = [&](int buf, const uint4 (&r)[UN]) {
+    auto stash = [&](int buf, int kc, const Raw (&r)[UNR]) {
 #pragma unroll
-        for (int i = 0; i < UN; i++)
-            if (tid + 256 * i < NP * ROWS * 4) *reinterpret_cast<uint4*>(img + buf * NP * PB + loffs[i]) = r[i];
+        for (int i = 0; i < UNR; i++) {
+            if constexpr (PRO == 0) {
+                if (tid + 256 * i < NP * ROWS * 4) *reinterpret_cast<uint4*>(img + buf * NP * PB + loffs[i]) = r[i].a;
+            } else {
+                if (tid + 256 * i >= ROWS * 8) continue;
+                const int ch = kc * 32 + ((tid + 256 * i) & 7) * 4;
+                const float4 ga = *reinterpret_cast<const float4*>(ptab + ch), p1 = *reinterpret_cast<const float4*>(ptab + NF + ch),
+                             mu = *reinterpret_cast<const float4*>(ptab + 2 * NF + ch), is = *reinterpret_cast<const float4*>(ptab + 3 * NF + ch);
+                const float g4[4] = {ga.x, ga.y, ga.z, ga.w}, q4[4] = {p1.x, p1.y, p1.z, p1.w}, m4[4] = {mu.x, mu.y, mu.z, mu.w}, i4[4] = {is.x, is.y, is.z, is.w};
+                const float xa[4] = {__uint_as_float(r[i].a.x), __uint_as_float(r[i].a.y), __uint_as_float(r[i].a.z), __uint_as_float(r[i].a.w)};
+                const float xb[4] = {__uint_as_float(r[i].b.x), __uint_as_float(r[i].b.y), __uint_as_float(r[i].b.z), __uint_as_float(r[i].b.w)};
+                float o[4];
+                uint2 hi, lo;
+                if constexpr (PRO == 1) {   // t_bn_apply<false>
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float v = g4[j] * ((xa[j] - m4[j]) * i4[j]) + q4[j] + xb[j];
+                        o[j] = v > 0.0f ? v : 0.0f;
+                    }
+                    _Float16 h[4], l[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { h[j] = (_Float16)o[j]; l[j] = (_Float16)(o[j] - (float)h[j]); }
+                    hi = make_uint2(__builtin_bit_cast(uint32_t, f16x2_t{h[0], h[1]}), __builtin_bit_cast(uint32_t, f16x2_t{h[2], h[3]}));
+                    lo = make_uint2(__builtin_bit_cast(uint32_t, f16x2_t{l[0], l[1]}), __builtin_bit_cast(uint32_t, f16x2_t{l[2], l[3]}));
+                    if (uok[i]) {
+                        *reinterpret_cast<float4*>(Pf.O + goff[i] + kc * 32) = make_float4(o[0], o[1], o[2], o[3]);
+                        split_store4(o, (goff[i] + kc * 32) / 4, Pf.p0, Pf.p1, nullptr);
+                    }
+                } else {                    // t_bn_bwd_apply<false>
+                    const float4 s1 = *reinterpret_cast<const float4*>(ptab + 4 * NF + ch);
+                    const float t4[4] = {s1.x, s1.y, s1.z, s1.w};
+                    const float xc[4] = {__uint_as_float(r[i].c.x), __uint_as_float(r[i].c.y), __uint_as_float(r[i].c.z), __uint_as_float(r[i].c.w)};
+                    float z[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float dz = xb[j] > 0.0f ? xa[j] : 0.0f;
+                        const float xh = (xc[j] - m4[j]) * i4[j];
+                        z[j] = dz;
+                        o[j] = g4[j] * i4[j] * (dz - q4[j] - xh * t4[j]);
+                    }
+                    uint32_t h[4], m[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        h[j] = bf_rne_bits(o[j]);
+                        m[j] = bf_rne_bits(o[j] - __uint_as_float(h[j] << 16));
+                    }
+                    hi = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                    lo = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+                    if (uok[i]) {
+                        const size_t i4x = (goff[i] + kc * 32) / 4;
+                        reinterpret_cast<uint2*>(Pf.p0)[i4x] = hi;
+                        reinterpret_cast<uint2*>(Pf.p1)[i4x] = lo;
+                        if (Pf.O) *reinterpret_cast<float4*>(Pf.O + goff[i] + kc * 32) = make_float4(z[0], z[1], z[2], z[3]);
+                    }
+                }
+                if (!uok[i]) { hi = make_uint2(0u, 0u); lo = hi; }   // rows of a missing second board
+                *reinterpret_cast<uint2*>(img + buf * NP * PB + loffs[i]) = hi;
+                *reinterpret_cast<uint2*>(img + buf * NP * PB + PB + loffs[i]) = lo;
+            }
+        }
     };
     {
-        uint4 r0[UN];
+        Raw r0[UNR];
         fetch(0, r0);
-        stash(0, r0);
+        stash(0, 0, r0);
     }
     __syncthreads();
     // per lane: byte offset of its fragment row for (loop tap, tile) inside a part of a slice
@@ -702,7 +861,7 @@ __global__ __launch_bounds__(256, 1) void t_conv_rs(Parts A, Parts Bp, float* __
     s16x8 a[MT][NP];
 
     for (int kc = 0; kc < 8; kc++) {
-        uint4 nx[UN];
+        Raw nx[UNR];
         if (kc + 1 < 8) fetch(kc + 1, nx);
         const uint8_t* bufc = img + (kc & 1) * NP * PB;
         {   // the fragments of tap 0 of this slice (the slice became visible with the barrier that ended the previous chunk)
@@ -713,27 +872,125 @@ __global__ __launch_bounds__(256, 1) void t_conv_rs(Parts A, Parts Bp, float* __
 #pragma unroll
                     for (int q = 0; q < NP; q++) a[mt][q] = *reinterpret_cast<const s16x8*>(bufc + q * PB + arow[0][mt]);
         }
-        rs_tap<AMODE, NP, 0>(bufc, kc, wsrc, loff, arow, bq, acc, a);
-        rs_tap<AMODE, NP, 1>(bufc, kc, wsrc, loff, arow, bq, acc, a);
-        rs_tap<AMODE, NP, 2>(bufc, kc, wsrc, loff, arow, bq, acc, a);
-        rs_tap<AMODE, NP, 3>(bufc, kc, wsrc, loff, arow, bq, acc, a);
-        rs_tap<AMODE, NP, 4>(bufc, kc, wsrc, loff, arow, bq, acc, a);
-        rs_tap<AMODE, NP, 5>(bufc, kc, wsrc, loff, arow, bq, acc, a);
-        rs_tap<AMODE, NP, 6>(bufc, kc, wsrc, loff, arow, bq, acc, a);
-        rs_tap<AMODE, NP, 7>(bufc, kc, wsrc, loff, arow, bq, acc, a);
-        rs_tap<AMODE, NP, 8>(bufc, kc, wsrc, loff, arow, bq, acc, a);
-        if (kc + 1 < 8) stash((kc + 1) & 1, nx);
+        rs_tap<AMODE, NP, 0, F16>(bufc, kc, wsrc, loff, arow, bq, acc, a);
+        rs_tap<AMODE, NP, 1, F16>(bufc, kc, wsrc, loff, arow, bq, acc, a);
+        rs_tap<AMODE, NP, 2, F16>(bufc, kc, wsrc, loff, arow, bq, acc, a);
+        rs_tap<AMODE, NP, 3, F16>(bufc, kc, wsrc, loff, arow, bq, acc, a);
+        rs_tap<AMODE, NP, 4, F16>(bufc, kc, wsrc, loff, arow, bq, acc, a);
+        rs_tap<AMODE, NP, 5, F16>(bufc, kc, wsrc, loff, arow, bq, acc, a);
+        rs_tap<AMODE, NP, 6, F16>(bufc, kc, wsrc, loff, arow, bq, acc, a);
+        rs_tap<AMODE, NP, 7, F16>(bufc, kc, wsrc, loff, arow, bq, acc, a);
+        rs_tap<AMODE, NP, 8, F16>(bufc, kc, wsrc, loff, arow, bq, acc, a);
+        if (kc + 1 < 8) stash((kc + 1) & 1, kc + 1, nx);
         __syncthreads();
     }
     // ---- C rows back in natural order: a lane holds 4 consecutive channels of one cell
+    if constexpr (FUSE == 0) {
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++) {
-        const int ci = rowcell[mt * 16 + c];
-        if (ci == 0xffff || (ci >> 8) >= nbv) continue;
-        float* out = C + (size_t)(m0 + (ci >> 8) * NPOS + (ci & 15) * 6 + ((ci >> 4) & 15)) * NF + wave * 64 + g * 4;
+        for (int mt = 0; mt < MT; mt++) {
+            const int ci = rowcell[mt * 16 + c];
+            if (ci == 0xffff || (ci >> 8) >= nbv) continue;
+            float* out = C + (size_t)(m0 + (ci >> 8) * NPOS + (ci & 15) * 6 + ((ci >> 4) & 15)) * NF + wave * 64 + g * 4;
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                if constexpr (F16) acc[mt][nt] *= oscale;
+                *reinterpret_cast<float4*>(out + nt * 16) = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+            }
+        }
+    } else if constexpr (FUSE == 2) {
+        // forward conv: the batch-norm statistics of its own output (t_bn_stats: per channel sum and sum of squares), per block
+        // of 2 boards, in double, cells of a lane first, then the 16 lanes of a channel group -> F.part[blockIdx][2][256]
+        double s[NT][4], ss[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
-            *reinterpret_cast<float4*>(out + nt * 16) = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+#pragma unroll
+            for (int e = 0; e < 4; e++) s[nt][e] = ss[nt][e] = 0.0;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const int ci = rowcell[mt * 16 + c];
+            const bool valid = !(ci == 0xffff || (ci >> 8) >= nbv);
+            if (valid) {
+                float* out = C + (size_t)(m0 + (ci >> 8) * NPOS + (ci & 15) * 6 + ((ci >> 4) & 15)) * NF + wave * 64 + g * 4;
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    if constexpr (F16) acc[mt][nt] *= oscale;
+                    *reinterpret_cast<float4*>(out + nt * 16) = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const double v = (double)acc[mt][nt][e];
+                        s[nt][e] += v;
+                        ss[nt][e] += v * v;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+#pragma unroll
+                for (int sft = 1; sft < 16; sft <<= 1) {
+                    s[nt][e] += __shfl_xor(s[nt][e], sft);
+                    ss[nt][e] += __shfl_xor(ss[nt][e], sft);
+                }
+                if (c == 0) {
+                    const int ch = wave * 64 + nt * 16 + g * 4 + e;
+                    F.part[((size_t)blockIdx.x * 2 + 0) * NF + ch] = s[nt][e];
+                    F.part[((size_t)blockIdx.x * 2 + 1) * NF + ch] = ss[nt][e];
+                }
+            }
+    } else {
+        double s[NT][4], sx[NT][4];
+        float4 mu[NT], is[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            mu[nt] = *reinterpret_cast<const float4*>(F.mean + wave * 64 + g * 4 + nt * 16);
+            is[nt] = *reinterpret_cast<const float4*>(F.istd + wave * 64 + g * 4 + nt * 16);
+#pragma unroll
+            for (int e = 0; e < 4; e++) s[nt][e] = sx[nt][e] = 0.0;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const int ci = rowcell[mt * 16 + c];
+            const bool valid = !(ci == 0xffff || (ci >> 8) >= nbv);
+            const size_t o = (size_t)(m0 + (valid ? (ci >> 8) * NPOS + (ci & 15) * 6 + ((ci >> 4) & 15) : 0)) * NF + wave * 64 + g * 4;
+            if (valid) {
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    float4 v = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+                    if (F.DS) {
+                        const float4 d = *reinterpret_cast<const float4*>(F.DS + o + nt * 16);
+                        v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+                    }
+                    *reinterpret_cast<float4*>(C + o + nt * 16) = v;
+                    const float4 a4 = *reinterpret_cast<const float4*>(F.Apost + o + nt * 16), y4 = *reinterpret_cast<const float4*>(F.Y + o + nt * 16);
+                    const float vv[4] = {v.x, v.y, v.z, v.w}, aa[4] = {a4.x, a4.y, a4.z, a4.w}, yy[4] = {y4.x, y4.y, y4.z, y4.w};
+                    const float mm[4] = {mu[nt].x, mu[nt].y, mu[nt].z, mu[nt].w}, ii[4] = {is[nt].x, is[nt].y, is[nt].z, is[nt].w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float dz = aa[e] > 0.0f ? vv[e] : 0.0f;
+                        s[nt][e] += (double)dz;
+                        sx[nt][e] += (double)dz * (double)((yy[e] - mm[e]) * ii[e]);
+                    }
+                }
+            }
+        }
+        // the 16 lanes c = 0..15 of a channel group hold different cells: butterfly over c, lane c = 0 writes
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+#pragma unroll
+                for (int sft = 1; sft < 16; sft <<= 1) {
+                    s[nt][e] += __shfl_xor(s[nt][e], sft);
+                    sx[nt][e] += __shfl_xor(sx[nt][e], sft);
+                }
+                if (c == 0) {
+                    const int ch = wave * 64 + nt * 16 + g * 4 + e;
+                    F.part[((size_t)blockIdx.x * 2 + 0) * NF + ch] = s[nt][e];
+                    F.part[((size_t)blockIdx.x * 2 + 1) * NF + ch] = sx[nt][e];
+                }
+            }
     }
 }
 
@@ -1174,7 +1431,8 @@ __global__ __launch_bounds__(1024) void t_bn_finalize(const double* __restrict__
 template <bool STEM>
 __global__ __launch_bounds__(256) void t_bn_apply(const float* __restrict__ Y, const float* __restrict__ mean, const float* __restrict__ istd,
                                                   const float* __restrict__ bn, const float* __restrict__ S, float* __restrict__ A, int M,
-                                                  uint16_t* __restrict__ p0, uint16_t* __restrict__ p1, uint16_t* __restrict__ p2)
+                                                  uint16_t* __restrict__ p0, uint16_t* __restrict__ p1, uint16_t* __restrict__ p2,
+                                                  uint16_t* __restrict__ q0 = nullptr, uint16_t* __restrict__ q1 = nullptr)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
     if (i >= (size_t)M * (NF / 4)) return;
@@ -1191,7 +1449,8 @@ __global__ __launch_bounds__(256) void t_bn_apply(const float* __restrict__ Y, c
         o[j] = v > 0.0f ? v : 0.0f;
     }
     reinterpret_cast<float4*>(A)[i] = make_float4(o[0], o[1], o[2], o[3]);
-    if (p0) split_store4(o, i, p0, p1, p2);  // operand parts of the next layer's forward GEMM
+    if (p0) split_store4(o, i, p0, p1, p2);  // bf16 parts: the weight-gradient GEMM's operand (and, with p2, the 6-pass forward conv's)
+    if (q0) split_store4_f16(o, i, q0, q1);  // fp16 pair: the next layer's 3-pass forward conv
 }
 
 // backward stage 1: dz = dOut * (Apost > 0); partial sums of dz and dz * xhat
@@ -1312,7 +1571,7 @@ __global__ __launch_bounds__(256) void t_bn_bwd_apply(const float* __restrict__ 
         z[j] = dz;
         o[j] = bn[ch] * istd[ch] * (dz - sums[ch] * inv_count - xh * (sums[NF + ch] * inv_count));
     }
-    reinterpret_cast<float4*>(dY)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if (dY) reinterpret_cast<float4*>(dY)[i] = make_float4(o[0], o[1], o[2], o[3]);
     if (dZ) reinterpret_cast<float4*>(dZ)[i] = make_float4(z[0], z[1], z[2], z[3]);
     if (p0) split_store4(o, i, p0, p1, nullptr);  // operand parts of the two gradient GEMMs
 }
@@ -1610,6 +1869,11 @@ bool g_gemm_bf16x3 = true;
 // which split-bf16 conv kernels: t_conv_rs (default) or the older t_conv_sb (AZR_TRAIN_GEMM=sb: kept as the second
 // implementation the tests compare against)
 bool g_conv_rs = true;
+// forward conv arithmetic: fp16 pairs, 3 passes (default) or three bf16 parts, 6 passes (AZR_TRAIN_FWD=bf16)
+bool g_fwd_f16 = true;
+constexpr float FWD_WSCALE = 1024.0f;   // the packed forward kernels are 2^10 * W: |w| < 64 stays inside fp16, a weight of 1e-4 keeps a normal low part
+bool g_fuse_bwd = true;
+bool g_fuse_apply = true;   // t_conv_rs<.., PRO>: the normalise kernels (t_bn_apply / t_bn_bwd_apply) computed in the consuming conv's staging path (AZR_TRAIN_FUSE_APPLY=0: separate kernels; same bits)   // t_conv_rs<2, 2, 1>: shortcut add + BN-backward stage 1 in the backward-data conv's epilogue (AZR_TRAIN_FUSE=0: separate kernels)
 
 struct TrainCtx {
     int BS = 0, blocks = 0, M = 0, L = 0, R = 0, nz = 0, kchunk = 0;
@@ -1626,6 +1890,7 @@ struct TrainCtx {
     double* part = nullptr;                  // [R][2*NG][256]
     float* wpart = nullptr;                  // split-K partials [nz][KC][256]
     uint16_t *ap[3] = {nullptr, nullptr, nullptr}, *dyp[2] = {nullptr, nullptr};          // bf16 parts of activations / gradients
+    uint16_t* af[2] = {nullptr, nullptr};    // fp16 pair (hi, lo) of the newest post-activation: the next forward conv's operand
     uint16_t *wpf[3] = {nullptr, nullptr, nullptr}, *wpb[2] = {nullptr, nullptr};        // packed kernels: forward / backward-data view
     float *pv0 = nullptr, *dpv = nullptr, *hstat = nullptr, *fpi = nullptr, *fv = nullptr, *h1 = nullptr, *vout = nullptr,
           *prob = nullptr, *lossb = nullptr, *hpart = nullptr, *cpart = nullptr, *loss = nullptr;
@@ -1683,6 +1948,9 @@ int ctx_ensure(azr_engine* h, int BS)
     // tuning switch, read when a training context is (re)built — never in the step path
     g_gemm_bf16x3 = !(getenv("AZR_TRAIN_GEMM") && strcmp(getenv("AZR_TRAIN_GEMM"), "f32") == 0);
     g_conv_rs = !(getenv("AZR_TRAIN_GEMM") && strcmp(getenv("AZR_TRAIN_GEMM"), "sb") == 0);
+    g_fuse_bwd = !(getenv("AZR_TRAIN_FUSE") && atoi(getenv("AZR_TRAIN_FUSE")) == 0);
+    g_fwd_f16 = !(getenv("AZR_TRAIN_FWD") && strcmp(getenv("AZR_TRAIN_FWD"), "bf16") == 0);
+    g_fuse_apply = !(getenv("AZR_TRAIN_FUSE_APPLY") && atoi(getenv("AZR_TRAIN_FUSE_APPLY")) == 0);
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(t_wgrad_rs), hipFuncAttributeMaxDynamicSharedMemorySize, Wg::LDS_BYTES));
     // a different batch size rebuilds the activation slabs but keeps the optimiser state
     std::vector<float> keep_m, keep_v;
@@ -1727,6 +1995,7 @@ int ctx_ensure(azr_engine* h, int BS)
     for (int q = 0; q < 3; q++) { TRY(dalloc(h, c, &c->ap[q], q < 2 ? act * c->L : act)); TRY(dalloc(h, c, &c->wpf[q], (size_t)2 * B * KC * NF)); }
     for (int q = 0; q < 2; q++) TRY(dalloc(h, c, &c->wpb[q], (size_t)2 * B * KC * NF));
     for (int q = 0; q < 2; q++) TRY(dalloc(h, c, &c->dyp[q], act));
+    for (int q = 0; q < 2; q++) TRY(dalloc(h, c, &c->af[q], act));
     TRY(dalloc(h, c, &c->pv0, M * 4)); TRY(dalloc(h, c, &c->dpv, M * 4)); TRY(dalloc(h, c, &c->hstat, (size_t)8));
     TRY(dalloc(h, c, &c->fpi, (size_t)BS * 84)); TRY(dalloc(h, c, &c->fv, (size_t)BS * 42)); TRY(dalloc(h, c, &c->h1, (size_t)BS * 256));
     TRY(dalloc(h, c, &c->vout, (size_t)BS)); TRY(dalloc(h, c, &c->prob, (size_t)BS * 43)); TRY(dalloc(h, c, &c->lossb, (size_t)BS * 2));
@@ -1828,11 +2097,12 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     auto Al = [&](int l) { return c->A + act * l; };
     const unsigned g4 = (unsigned)((act / 4 + 255) / 256);
     const bool sb = g_gemm_bf16x3 && M % K3 == 0;  // split-bf16 conv GEMMs (the stem, K = 144, stays on the fp32 MFMA)
+    const bool f16 = sb && g_conv_rs && g_fwd_f16; // forward conv: fp16 pairs, 3 passes
     auto Wpf = [&](int l) { const size_t o = (size_t)(l - 1) * KC * NF; return Parts{{c->wpf[0] + o, c->wpf[1] + o, c->wpf[2] + o}}; };
     auto Wpb = [&](int l) { const size_t o = (size_t)(l - 1) * KC * NF; return Parts{{c->wpb[0] + o, c->wpb[1] + o, nullptr}}; };
     if (sb) {
         const dim3 pg((unsigned)((wn_ / 8 + 255) / 256), 2 * B);
-        hipLaunchKernelGGL((t_pack_w<3>), pg, dim3(256), 0, st, w, 0, c->wpf[0], c->wpf[1], c->wpf[2]);
+        hipLaunchKernelGGL((t_pack_w<3>), pg, dim3(256), 0, st, w, 0, c->wpf[0], c->wpf[1], c->wpf[2], f16 ? FWD_WSCALE : 0.0f);
         hipLaunchKernelGGL((t_pack_w<2>), pg, dim3(256), 0, st, w, 1, c->wpb[0], c->wpb[1], (uint16_t*)nullptr);
     }
 
@@ -1849,20 +2119,44 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     // (each layer's normalise kernel also writes the three bf16 parts of its output: the next conv's A operand)
     auto Ap = [&](int l) { return Parts{{c->ap[0] + act * l, c->ap[1] + act * l, c->ap[2]}}; };   // parts of the post-activation of layer l
     hipLaunchKernelGGL((t_bn_apply<true>), dim3(g4), dim3(256), 0, st, Yl(0), c->mean, c->istd, w + OFF_STEM_BN, (const float*)nullptr, Al(0), M,
-                       sb ? c->ap[0] : nil16, c->ap[1], c->ap[2]);
+                       sb ? c->ap[0] : nil16, c->ap[1], f16 ? nil16 : c->ap[2], f16 ? c->af[0] : nil16, c->af[1]);
+    // Fused mode (fp16 forward + epilogue statistics + staging-path normalise): layer l's normalise step is not a kernel of its own
+    // — the forward conv of layer l + 1 computes A_l = relu(BN(Y_l) (+ S)) while it stages its operand and writes A_l and its
+    // bf16 parts out; only the stem (row-wise BN) and the last layer (the heads read it) keep t_bn_apply.
+    const bool fap = f16 && g_fuse_bwd && g_fuse_apply;
     for (int l = 1; l < c->L; l++) {
         float* bn = Wl(l) + (size_t)9 * NF * NF;
         const float* S = (l % 2 == 0) ? Al(l - 2) : nullptr;  // second conv of a block adds the block input
-        if (sb) {  // conv = implicit im2col x W, 6-pass split bf16 (fp32-exact products)
-            if (g_conv_rs) hipLaunchKernelGGL((t_conv_rs<1, 3>), dim3((BS + 1) / 2), dim3(256), 0, st, Ap(l - 1), Wpf(l), Yl(l), BS);
+        int fwd_parts = 0;
+        if (sb) {  // conv = implicit im2col x W in split precision (fp32-exact products)
+            if (fap && l >= 2) {   // operand computed on the way in (layer l - 1's normalise step), statistics of the output on the way out
+                fwd_parts = (BS + 1) / 2;
+                const int m = l - 1;
+                hipLaunchKernelGGL((t_conv_rs<1, 2, 2, true, 1>), dim3(fwd_parts), dim3(256), 0, st, Parts{{nullptr, nullptr, nullptr}}, Wpf(l), Yl(l), BS,
+                                   BwdFuse{nullptr, nullptr, nullptr, nullptr, nullptr, c->part}, 1.0f / FWD_WSCALE,
+                                   ProFuse{Yl(m), (m % 2 == 0) ? (const float*)Al(m - 2) : (const float*)nullptr, nullptr, c->mean + m * NF, c->istd + m * NF,
+                                           Wl(m) + (size_t)9 * NF * NF, nullptr, 0.0f, Al(m), const_cast<uint16_t*>(Ap(m).p[0]), const_cast<uint16_t*>(Ap(m).p[1])});
+            } else if (f16 && g_fuse_bwd) {   // + the batch statistics of the output, per block of 2 boards
+                fwd_parts = (BS + 1) / 2;
+                hipLaunchKernelGGL((t_conv_rs<1, 2, 2, true>), dim3(fwd_parts), dim3(256), 0, st, Parts{{c->af[0], c->af[1], nullptr}}, Wpf(l), Yl(l), BS,
+                                   BwdFuse{nullptr, nullptr, nullptr, nullptr, nullptr, c->part}, 1.0f / FWD_WSCALE, ProFuse{});
+            } else if (f16) hipLaunchKernelGGL((t_conv_rs<1, 2, 0, true>), dim3((BS + 1) / 2), dim3(256), 0, st, Parts{{c->af[0], c->af[1], nullptr}}, Wpf(l), Yl(l), BS,
+                                        BwdFuse{}, 1.0f / FWD_WSCALE, ProFuse{});
+            else if (g_conv_rs) hipLaunchKernelGGL((t_conv_rs<1, 3>), dim3((BS + 1) / 2), dim3(256), 0, st, Ap(l - 1), Wpf(l), Yl(l), BS, BwdFuse{}, 1.0f, ProFuse{});
             else hipLaunchKernelGGL((t_conv_sb<1, 3, 1>), dim3(2, (M + 63) / 64), dim3(256), 0, st, Ap(l - 1), Wpf(l), Yl(l), M);
         } else gemm<false, false, 64, 1, 0>(st, Al(l - 1), KC, Wl(l), NF, Yl(l), NF, M, NF, KC);
-        hipLaunchKernelGGL((t_bn_stats<false>), dim3(R), dim3(1024), 0, st, Yl(l), M, c->part);
-        if (dp) TRY(reduce_parts(2));
-        hipLaunchKernelGGL((t_bn_finalize<false>), dim3(8), dim3(1024), 0, st, dp ? c->red : c->part, dp ? 1 : R, (double)Mg, c->mean + l * NF,
+        const int Rf = fwd_parts ? fwd_parts : R;
+        if (!fwd_parts) hipLaunchKernelGGL((t_bn_stats<false>), dim3(R), dim3(1024), 0, st, Yl(l), M, c->part);
+        if (dp) {
+            hipLaunchKernelGGL(t_parts_sum, dim3(2), dim3(256), 0, st, c->part, Rf, 2, c->red);
+            TRY(dp_allreduce(h, c, c->red, (size_t)2 * NF, 1));
+        }
+        hipLaunchKernelGGL((t_bn_finalize<false>), dim3(8), dim3(1024), 0, st, dp ? c->red : c->part, dp ? 1 : Rf, (double)Mg, c->mean + l * NF,
                            c->istd + l * NF, bn);
+        if (fap && l + 1 < c->L) continue;   // the next conv normalises this layer's output itself
         hipLaunchKernelGGL((t_bn_apply<false>), dim3(g4), dim3(256), 0, st, Yl(l), c->mean + l * NF, c->istd + l * NF, bn, S, Al(l), M,
-                           (sb && l + 1 < c->L) ? const_cast<uint16_t*>(Ap(l).p[0]) : nil16, const_cast<uint16_t*>(Ap(l).p[1]), c->ap[2]);
+                           (sb && l + 1 < c->L) ? const_cast<uint16_t*>(Ap(l).p[0]) : nil16, const_cast<uint16_t*>(Ap(l).p[1]), f16 ? nil16 : c->ap[2],
+                           (f16 && l + 1 < c->L) ? c->af[0] : nil16, c->af[1]);
     }
     const float* H = Al(c->L - 1);
     hipLaunchKernelGGL(t_head_conv, grid1((size_t)M, 4), dim3(256), 0, st, H, hp, c->pv0, M);
@@ -1884,31 +2178,66 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     hipLaunchKernelGGL(t_head_conv_bwd_finalize, dim3(1), dim3(256), 0, st, c->cpart, R, gh);
     const float invM = 1.0f / (float)Mg;
     const size_t wn = wn_;
+    // (t_conv_rs<2, 2, 1>, the backward-data conv of layer l, leaves stage 1 of layer l - 1's batch-norm backward behind: its
+    //  block partials are then already in c->part, `fused_parts` blocks of them)
+    int fused_parts = 0;
+    const bool fuse = sb && g_conv_rs && g_fuse_bwd;
     for (int l = c->L - 1; l >= 1; l--) {
         // gradient w.r.t. this layer's post-activation output: G for the second conv of a block, DT for the first
         const bool second = (l % 2 == 0);
         const float* dOut = second ? c->G : c->DT;
         float* bn = Wl(l) + wn;
         float* gbn = Gl(l) + wn;
-        hipLaunchKernelGGL((t_bn_bwd_stats<false>), dim3(R), dim3(1024), 0, st, dOut, Al(l), Yl(l), c->mean + l * NF, c->istd + l * NF, M, c->part);
-        if (dp) TRY(reduce_parts(2));
-        hipLaunchKernelGGL((t_bn_bwd_finalize<false>), dim3(8), dim3(1024), 0, st, dp ? c->red : c->part, dp ? 1 : R, gbn, c->sums, gscale);
+        const int Rl = fused_parts ? fused_parts : R;
+        if (!fused_parts)
+            hipLaunchKernelGGL((t_bn_bwd_stats<false>), dim3(R), dim3(1024), 0, st, dOut, Al(l), Yl(l), c->mean + l * NF, c->istd + l * NF, M, c->part);
+        if (dp) {
+            hipLaunchKernelGGL(t_parts_sum, dim3(2), dim3(256), 0, st, c->part, Rl, 2, c->red);
+            TRY(dp_allreduce(h, c, c->red, (size_t)2 * NF, 1));
+        }
+        hipLaunchKernelGGL((t_bn_bwd_finalize<false>), dim3(8), dim3(1024), 0, st, dp ? c->red : c->part, dp ? 1 : Rl, gbn, c->sums, gscale);
+        float* dIn = second ? c->DT : c->G;
+        const Parts dyP{{c->dyp[0], c->dyp[1], nullptr}};
+        const Parts apP{{Ap(l - 1).p[0], Ap(l - 1).p[1], nullptr}};
+        if (fuse && g_fuse_apply) {
+            // dY is computed in the backward-data conv's staging path (t_bn_bwd_apply's arithmetic; its two bf16 parts and, where the
+            // layer closes a block, dz = the shortcut gradient DS are written out on the way), so that conv runs FIRST and the
+            // weight-gradient GEMM reads the parts it left behind
+            const ProFuse pf{dOut, Al(l), Yl(l), c->mean + l * NF, c->istd + l * NF, bn, c->sums, invM, second ? c->DS : (float*)nullptr, c->dyp[0], c->dyp[1]};
+            fused_parts = 0;
+            if (l >= 2) {
+                fused_parts = (BS + 1) / 2;
+                hipLaunchKernelGGL((t_conv_rs<2, 2, 1, false, 2>), dim3(fused_parts), dim3(256), 0, st, Parts{{nullptr, nullptr, nullptr}}, Wpb(l), dIn, BS,
+                                   BwdFuse{second ? (const float*)nullptr : (const float*)c->DS, Al(l - 1), Yl(l - 1), c->mean + (l - 1) * NF,
+                                           c->istd + (l - 1) * NF, c->part}, 1.0f, pf);
+            } else {
+                hipLaunchKernelGGL((t_conv_rs<2, 2, 0, false, 2>), dim3((BS + 1) / 2), dim3(256), 0, st, Parts{{nullptr, nullptr, nullptr}}, Wpb(l), dIn, BS, BwdFuse{}, 1.0f, pf);
+                if (!second) hipLaunchKernelGGL(t_add, dim3(g4), dim3(256), 0, st, dIn, c->DS, act / 4);
+            }
+            hipLaunchKernelGGL(t_wgrad_rs, dim3(64 * c->wg_slices), dim3(64), Wg::LDS_BYTES, st, apP, dyP, c->wpart, M, c->wg_slices, c->wg_rows);
+            hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, c->wg_slices, wn, Gl(l));
+            continue;
+        }
+        // (the split-bf16 kernels read the two parts of dY; its fp32 image is only written for the fp32-MFMA GEMMs)
         hipLaunchKernelGGL((t_bn_bwd_apply<false>), dim3(g4), dim3(256), 0, st, dOut, Al(l), Yl(l), c->mean + l * NF, c->istd + l * NF, bn, c->sums,
-                           invM, c->dY, second ? c->DS : (float*)nullptr, M, sb ? c->dyp[0] : nil16, c->dyp[1]);
+                           invM, sb ? (float*)nullptr : c->dY, second ? c->DS : (float*)nullptr, M, sb ? c->dyp[0] : nil16, c->dyp[1]);
         // dW = col(input)^T x dY  (implicit im2col, split-K over the M rows)
         if (sb) {
-            if (g_conv_rs)
-                hipLaunchKernelGGL(t_wgrad_rs, dim3(64 * c->wg_slices), dim3(64), Wg::LDS_BYTES, st, Parts{{Ap(l - 1).p[0], Ap(l - 1).p[1], nullptr}},
-                                   Parts{{c->dyp[0], c->dyp[1], nullptr}}, c->wpart, M, c->wg_slices, c->wg_rows);
-            else
-                gemm_sb<true, false, 128, 1, 0, 2>(st, Parts{{Ap(l - 1).p[0], Ap(l - 1).p[1], nullptr}}, KC, Parts{{c->dyp[0], c->dyp[1], nullptr}}, NF, c->wpart,
-                                                   NF, KC, NF, M, c->nz, c->kchunk, wn);
+            if (g_conv_rs) hipLaunchKernelGGL(t_wgrad_rs, dim3(64 * c->wg_slices), dim3(64), Wg::LDS_BYTES, st, apP, dyP, c->wpart, M, c->wg_slices, c->wg_rows);
+            else gemm_sb<true, false, 128, 1, 0, 2>(st, apP, KC, dyP, NF, c->wpart, NF, KC, NF, M, c->nz, c->kchunk, wn);
         } else gemm<true, false, 128, 1, 0>(st, Al(l - 1), KC, c->dY, NF, c->wpart, NF, KC, NF, M, c->nz, c->kchunk, wn);
         hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, (sb && g_conv_rs) ? c->wg_slices : c->nz, wn, Gl(l));
         // d(input) = transposed conv of dY with W: the same implicit GEMM with negated taps and W read as [tap][co] x [ci]
-        float* dIn = second ? c->DT : c->G;
-        if (sb && g_conv_rs) hipLaunchKernelGGL((t_conv_rs<2, 2>), dim3((BS + 1) / 2), dim3(256), 0, st, Parts{{c->dyp[0], c->dyp[1], nullptr}}, Wpb(l), dIn, BS);
-        else if (sb) hipLaunchKernelGGL((t_conv_sb<2, 2, 1>), dim3(2, (M + 63) / 64), dim3(256), 0, st, Parts{{c->dyp[0], c->dyp[1], nullptr}}, Wpb(l), dIn, M);
+        fused_parts = 0;
+        if (fuse && l >= 2) {   // + the shortcut gradient (first conv of a block), + stage 1 of layer l - 1's BN backward
+            fused_parts = (BS + 1) / 2;
+            hipLaunchKernelGGL((t_conv_rs<2, 2, 1>), dim3(fused_parts), dim3(256), 0, st, dyP, Wpb(l), dIn, BS,
+                               BwdFuse{second ? (const float*)nullptr : (const float*)c->DS, Al(l - 1), Yl(l - 1), c->mean + (l - 1) * NF,
+                                       c->istd + (l - 1) * NF, c->part}, 1.0f, ProFuse{});
+            continue;
+        }
+        if (sb && g_conv_rs) hipLaunchKernelGGL((t_conv_rs<2, 2>), dim3((BS + 1) / 2), dim3(256), 0, st, dyP, Wpb(l), dIn, BS, BwdFuse{}, 1.0f, ProFuse{});
+        else if (sb) hipLaunchKernelGGL((t_conv_sb<2, 2, 1>), dim3(2, (M + 63) / 64), dim3(256), 0, st, dyP, Wpb(l), dIn, M);
         else gemm<false, true, 64, 2, 3>(st, c->dY, KC, Wl(l), NF, dIn, NF, M, NF, KC);
         if (!second) hipLaunchKernelGGL(t_add, dim3(g4), dim3(256), 0, st, dIn, c->DS, act / 4);  // + shortcut gradient
     }

@@ -100,15 +100,21 @@ def tf_adam(w, g, m, v, t, k):
     return np.where(tr, w2, w), np.where(tr, m2, m), np.where(tr, v2, v)
 
 
-@pytest.mark.parametrize("blocks,bs,gemm", [(1, 16, "split"), (2, 64, "split"), (2, 64, "sb"), (2, 64, "f32"), (1, 10, "split")])
+@pytest.mark.parametrize("blocks,bs,gemm", [(1, 16, "split"), (2, 64, "split"), (2, 64, "r2"), (2, 64, "sb"), (2, 64, "f32"), (1, 10, "split"), (2, 48, "split")])
 def test_step_matches_torch_graph(blocks, bs, gemm, monkeypatch):
-    """gemm = "split": the split-bf16 conv GEMMs (default: t_conv_rs, 2 boards per block in border-class row order);
-    "sb": the same arithmetic in the older 64-row tiles (AZR_TRAIN_GEMM=sb); "f32": the fp32-MFMA GEMMs
-    (AZR_TRAIN_GEMM=f32); batch 10 (42 * 10 rows, not a multiple of the 32-deep k-tile) takes the fp32 kernels by itself"""
+    """gemm = "split": the default step — t_conv_rs (2 boards per block in border-class row order) with the forward conv on fp16
+    pairs (3 passes), the backward GEMMs on two bf16 parts, the normalise / statistics kernels fused into the convs' staging
+    paths and epilogues; "r2": the same kernels as round 2 ran them (6-pass bf16 forward, separate normalise kernels:
+    AZR_TRAIN_FWD=bf16, AZR_TRAIN_FUSE=0); "sb": the older 64-row tiles (AZR_TRAIN_GEMM=sb); "f32": the fp32-MFMA GEMMs
+    (AZR_TRAIN_GEMM=f32); batch 10 (42 * 10 rows, not a multiple of the 32-deep k-tile) takes the fp32 kernels by itself; batch
+    48: 24 conv blocks of 2 boards, 3 weight-gradient row slices"""
+    for k in ("AZR_TRAIN_GEMM", "AZR_TRAIN_FWD", "AZR_TRAIN_FUSE", "AZR_TRAIN_FUSE_APPLY"):
+        monkeypatch.delenv(k, raising=False)
     if gemm in ("f32", "sb"):
         monkeypatch.setenv("AZR_TRAIN_GEMM", gemm)
-    else:
-        monkeypatch.delenv("AZR_TRAIN_GEMM", raising=False)
+    if gemm == "r2":
+        monkeypatch.setenv("AZR_TRAIN_FWD", "bf16")
+        monkeypatch.setenv("AZR_TRAIN_FUSE", "0")
     P = pkg()
     flat = T.make_net_flat(blocks, seed=11, perturb_bn=True)
     # the first record seed whose float64 forward keeps every ReLU input at least 1e-6 away from zero: the gradient
@@ -151,6 +157,29 @@ def test_step_matches_torch_graph(blocks, bs, gemm, monkeypatch):
     pi2, v2 = eng2.predict(x)
     assert (pi.view(np.uint32) == pi2.view(np.uint32)).all() and (v == v2).all()
     eng.close(); eng2.close()
+
+
+def test_fused_normalise_kernels_change_no_bit(monkeypatch):
+    """the normalise steps computed inside the consuming convs' staging paths (t_conv_rs<.., PRO>; default) against the same
+    arithmetic as kernels of their own (AZR_TRAIN_FUSE_APPLY=0): same formula, same inputs, same statistics -> the weights after
+    three optimiser steps are equal bit for bit."""
+    P = pkg()
+    blocks = 2
+    flat = T.make_net_flat(blocks, seed=5, perturb_bn=True)
+    out = {}
+    for bs in (64, 48):
+        rec = records(3 * bs, seed=17)
+        for mode in ("1", "0"):
+            monkeypatch.setenv("AZR_TRAIN_FUSE_APPLY", mode)
+            eng = P.Engine(8, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64)
+            eng.set_weights(flat)
+            losses = [eng.train_batch(rec[t * bs:(t + 1) * bs]) for t in range(3)]
+            out[mode] = (eng.get_weights(), eng.train_grads(), losses)
+            eng.close()
+        assert out["1"][2] == out["0"][2], (bs, out["1"][2], out["0"][2])
+        assert (out["1"][1].view(np.uint32) == out["0"][1].view(np.uint32)).all(), bs
+        assert (out["1"][0].view(np.uint32) == out["0"][0].view(np.uint32)).all(), bs
+        assert np.abs(out["1"][0] - flat).max() > 1e-3
 
 
 @pytest.mark.parametrize("blocks,bs", [(1, 16), (2, 64)])
