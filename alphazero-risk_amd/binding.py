@@ -48,6 +48,15 @@ class Counters(C.Structure):
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)   # azr_allreduce_fn
 
 
+def dp_unique_id():
+    """azr_dp_unique_id: the 128-byte id rank 0 draws and hands to the other ranks"""
+    b = (C.c_uint8 * 128)()
+    rc = load_library().azr_dp_unique_id(b)
+    if rc:
+        raise AzrError(rc, "azr_dp_unique_id: RCCL is not available")
+    return bytes(b)
+
+
 def lib_path():
     return os.path.join(CSRC, "libazr_hip.so")
 
@@ -65,7 +74,7 @@ EXPORTS = [
     "azr_engine_new_games", "azr_engine_set_states", "azr_engine_get_states", "azr_engine_set_rng", "azr_engine_get_rng",
     "azr_engine_valid_moves", "azr_engine_make_moves", "azr_engine_status", "azr_engine_encode",
     "azr_nn_param_count", "azr_nn_init_random", "azr_nn_set_weights", "azr_nn_get_weights", "azr_nn_load", "azr_nn_save",
-    "azr_nn_predict", "azr_nn_train", "azr_nn_train_dp", "azr_nn_train_batch", "azr_nn_train_grads", "azr_nn_train_reset", "azr_mcts_clear", "azr_mcts_trim", "azr_mcts_simulate", "azr_mcts_begin", "azr_mcts_leaves",
+    "azr_nn_predict", "azr_nn_train", "azr_nn_train_dp", "azr_dp_unique_id", "azr_dp_init", "azr_dp_shutdown", "azr_nn_train_batch", "azr_nn_train_grads", "azr_nn_train_reset", "azr_mcts_clear", "azr_mcts_trim", "azr_mcts_simulate", "azr_mcts_begin", "azr_mcts_leaves",
     "azr_mcts_apply", "azr_mcts_root_stats", "azr_mcts_policy", "azr_mcts_pick", "azr_selfplay_start", "azr_selfplay_start_games", "azr_selfplay_start_from_states",
     "azr_selfplay_run", "azr_selfplay_counters", "azr_samples_drain", "azr_samples_device_view", "azr_samples_copy_device", "azr_profile_last_run",
     "azr_device_synchronize", "azr_debug_tower_clock", "azr_debug_tower_trace", "azr_debug_tower_plan", "azr_arena_start", "azr_arena_run", "azr_arena_results", "azr_arena_log",
@@ -101,6 +110,9 @@ def load_library():
         L.azr_nn_train_dp.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN,
                                       C.c_void_p, C.c_void_p, C.c_void_p]
         L.azr_nn_train_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.azr_dp_unique_id.argtypes = [C.c_void_p]
+        L.azr_dp_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.azr_dp_shutdown.argtypes = [C.c_void_p]
         L.azr_nn_train_grads.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.azr_nn_train_reset.argtypes = [C.c_void_p]
         L.azr_selfplay_start.argtypes = [C.c_void_p, C.c_uint32]
@@ -269,9 +281,26 @@ class Engine:
                                       _p(lp), _p(lv)))
         return [(float(lp[e]), float(lv[e])) for e in range(epochs)], int(st[0])
 
+    def dp_init(self, rank, world, id128):
+        """azr_dp_init: this handle's RCCL communicator (collective over the `world` processes); id128 = dp_unique_id() of rank 0"""
+        b = (C.c_uint8 * 128).from_buffer_copy(bytes(id128))
+        self._chk(self.L.azr_dp_init(self.h, rank, world, b))
+
+    def dp_shutdown(self):
+        self._chk(self.L.azr_dp_shutdown(self.h))
+
     def train_dp(self, rec265, epochs, allreduce, rank, world, batch_size=512, rng_state=None):
         """azr_nn_train_dp: this rank's share of a data-parallel AlphaZeroNNId::train.  allreduce(device_ptr, count, dtype)
-        sums a device buffer over the ranks in place (dtype 0 = float32, 1 = float64); see shard.make_allreduce."""
+        sums a device buffer over the ranks in place (dtype 0 = float32, 1 = float64); see shard.make_allreduce.  allreduce = None:
+        the handle's own RCCL communicator (dp_init), every sum in stream order."""
+        if allreduce is None:
+            r = np.ascontiguousarray(rec265, np.uint8).reshape(-1, 265)
+            lp = np.zeros(max(epochs, 1), np.float32)
+            lv = np.zeros(max(epochs, 1), np.float32)
+            st = np.array([rng_state if rng_state is not None else 1], np.uint32)
+            self._chk(self.L.azr_nn_train_dp(self.h, _p(r), len(r), epochs, batch_size, _p(st) if rng_state is not None else None, rank, world,
+                                             C.cast(None, ALLREDUCE_FN), None, _p(lp), _p(lv)))
+            return [(float(lp[e]), float(lv[e])) for e in range(epochs)], int(st[0])
         r = np.ascontiguousarray(rec265, np.uint8).reshape(-1, 265)
         lp = np.zeros(max(epochs, 1), np.float32)
         lv = np.zeros(max(epochs, 1), np.float32)

@@ -982,6 +982,7 @@ extern "C" int azr_engine_destroy(azr_engine* h)
     for (void* p : h->tree2) if (p) hipFree(p);
     if (d.leaf_list) hipFree(d.leaf_list);
     if (d.leaf_count) hipFree(d.leaf_count);
+    dp_free(h);
     train_free(h);
     net_free(h);
     for (hipEvent_t e : h->ev) hipEventDestroy(e);

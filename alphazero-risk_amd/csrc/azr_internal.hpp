@@ -119,6 +119,8 @@ struct azr_engine {
     hipEvent_t arena_ev = nullptr;   // two-net arena: the opponent's net launch (on ITS stream) done -> this stream may go on
     bool sp_tail = false;         // quota self-play: no game is left to start, slots go idle -> compacted net batches
     void* train = nullptr;        // azr_train.hip: optimiser state + activation slabs, created by the first azr_nn_train*
+    void* dp_comm = nullptr;      // azr_dp_init: this handle's RCCL communicator (ncclComm_t), rank and world
+    int dp_rank = 0, dp_world = 0;
 };
 
 namespace azr {
@@ -137,4 +139,5 @@ int net_fx_upload(azr_engine* h, const float* fold_host);
 int net_fx_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st);
 // train (azr_train.hip)
 void train_free(azr_engine* h);
+void dp_free(azr_engine* h);
 }  // namespace azr

@@ -20,8 +20,10 @@
 // 1.8 GB for the 41 conv layers of B = 20 — sized for 288 GB of HBM, nothing is recomputed.
 // Reductions (BN statistics, bias / BN / head gradients, split-K) are two-stage and atomic-free: a step is
 // bit-reproducible.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <rccl/rccl.h>   // types and enumerators only: the library is bound at run time (rccl_api below)
 #include <stdint.h>
 #include <string.h>
 
@@ -995,6 +997,266 @@ __global__ __launch_bounds__(256, 1) void t_conv_rs(Parts A, Parts Bp, float* __
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// t_conv_q: the same conv GEMMs for SMALL batches — a rank's 64-record share of a data-parallel minibatch, or a small
+// minibatch.  t_conv_rs gives a CU 2 boards x 256 channels: 32 blocks at 64 records, an eighth of the chip, and the kernel takes
+// as long as for 512 records (a block's serial work sets the time).  Here a block is ONE board x 64 output channels
+// (blockIdx = board * 4 + channel group: 256 blocks at 64 records), and its 4 waves split K: wave w owns the 32-channel slices
+// w and w + 4 of the board (2 x 9 k-steps), staged privately by the wave itself (no barrier until the end), its partial sums
+// [48 rows x 64 channels] meet the other three waves' in LDS and are added in wave order (fixed: bit-reproducible); wave w
+// then finishes column tile w (16 channels): store, and the same epilogue / staging-path fusions as t_conv_rs (FUSE, PRO;
+// the side outputs of PRO are written by channel group 0 only).  One board = rows in natural order, 3 row tiles, no skipped
+// (tile, tap) pairs.  Operands: two parts (fp16 pair with F16, else bf16 hi / mid), 3 passes.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Rq {
+    static constexpr int ROWS = 42, MT = 3, ZR = 48, NT = 4, RING = 3, NP = 2;
+    static constexpr int CHB = 80;                       // bytes per row of a 32-channel slice (64 + 16 pad)
+    static constexpr int PB = (ZR + 1) * CHB;            // one part of one slice, incl. the zero row
+    static constexpr int WIMG = 2 * NP * PB;             // a wave's two slices
+    static constexpr int RED = 4 * MT * NT * 64 * 16;    // the four waves' partial sums (f32x4 per lane)
+    static constexpr int LDS = (4 * WIMG > RED ? 4 * WIMG : RED);
+};
+
+template <int AMODE, int FUSE, bool F16, int PRO>
+__global__ __launch_bounds__(256, 1) void t_conv_q(Parts A, Parts Bp, float* __restrict__ C, int boards, BwdFuse F, float oscale, ProFuse Pf)
+{
+    constexpr int ROWS = Rq::ROWS, MT = Rq::MT, ZR = Rq::ZR, NT = Rq::NT, RING = Rq::RING, NP = Rq::NP, CHB = Rq::CHB, PB = Rq::PB;
+    constexpr uint32_t KB = Rs::KB;
+    __shared__ __attribute__((aligned(16))) uint8_t img[Rq::LDS];
+    __shared__ uint8_t taprow[9 * ZR];
+    __shared__ __attribute__((aligned(16))) float ptab[PRO ? 5 * NF : 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int board = blockIdx.x >> 2, cq = blockIdx.x & 3, m0 = board * NPOS;
+    (void)boards;
+
+    // ---- weight ring: this wave's first two k-steps (slice `wave`, taps 0 and 1) fly while the tables are built
+    __amdgpu_buffer_rsrc_t wsrc[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) wsrc[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Bp.p[q]), (short)0, (int)(WPACK * 2), 0x00020000);
+    const uint32_t loff = (uint32_t)((cq * NT) * 64 + lane) * 16u;
+    u32x4 bq[RING][NP][NT];
+    auto kstep_off = [&](int s2) { return (uint32_t)((s2 % 9) * 8 + wave + 4 * (s2 / 9)) * KB; };   // k-step s2 of this wave: tap s2 % 9 of slice wave + 4 (s2 / 9)
+#pragma unroll
+    for (int s2 = 0; s2 < RING - 1; s2++)
+#pragma unroll
+        for (int q = 0; q < NP; q++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) bq[s2][q][nt] = __builtin_amdgcn_raw_buffer_load_b128(wsrc[q], loff + nt * 1024, (int)kstep_off(s2), 0);
+
+    // ---- tables: source row of (geometric tap, row); pad rows and out-of-board taps read the zero row
+    for (int i = tid; i < 9 * ZR; i += 256) {
+        const int t = i / ZR, r = i - t * ZR;
+        int src = ZR;
+        if (r < ROWS) {
+            const int y = r / 6 + t / 3 - 1, x = r % 6 + t % 3 - 1;
+            if ((unsigned)y < 7u && (unsigned)x < 6u) src = y * 6 + x;
+        }
+        taprow[i] = (uint8_t)src;
+    }
+    if constexpr (PRO != 0) {
+        for (int i = tid; i < NF; i += 256) {
+            ptab[i] = Pf.bn[i];
+            ptab[2 * NF + i] = Pf.mean[i];
+            ptab[3 * NF + i] = Pf.istd[i];
+            if constexpr (PRO == 1) ptab[NF + i] = Pf.bn[NF + i];
+            else { ptab[NF + i] = Pf.sums[i] * Pf.inv_count; ptab[4 * NF + i] = Pf.sums[NF + i] * Pf.inv_count; }
+        }
+    }
+    uint8_t* wimg = img + wave * Rq::WIMG;   // this wave's two slices: [slice][part][row][80 B]
+    for (int i = lane; i < 2 * NP * (CHB / 4); i += 64) {   // their zero rows
+        const int sp = i / (CHB / 4), w4 = i % (CHB / 4);
+        reinterpret_cast<uint32_t*>(wimg + sp * PB + ZR * CHB)[w4] = 0u;
+    }
+    __syncthreads();
+
+    // ---- the wave stages its two 32-channel slices itself (kc = wave, wave + 4)
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++) {
+        const int kc = wave + 4 * sl;
+        uint8_t* dst = wimg + sl * NP * PB;
+        if constexpr (PRO == 0) {
+            constexpr int UNITS = NP * ROWS * 4;   // (part, row, 16-byte segment)
+#pragma unroll
+            for (int i = 0; i < (UNITS + 63) / 64; i++) {
+                const int u = lane + 64 * i;
+                if (u < UNITS) {
+                    const int q = u / (ROWS * 4), rem = u - q * (ROWS * 4), r = rem >> 2, seg = rem & 3;
+                    *reinterpret_cast<uint4*>(dst + q * PB + r * CHB + seg * 16) =
+                        *reinterpret_cast<const uint4*>(A.p[q] + (size_t)(m0 + r) * NF + kc * 32 + seg * 8);
+                }
+            }
+        } else {
+            constexpr int UNITS = ROWS * 8;        // (row, 4 channels)
+#pragma unroll
+            for (int i = 0; i < (UNITS + 63) / 64; i++) {
+                const int u = lane + 64 * i;
+                if (u >= UNITS) continue;
+                const int r = u >> 3, seg = u & 7, ch = kc * 32 + seg * 4;
+                const size_t go = (size_t)(m0 + r) * NF + ch;
+                const float4 ga = *reinterpret_cast<const float4*>(ptab + ch), p1 = *reinterpret_cast<const float4*>(ptab + NF + ch),
+                             mu = *reinterpret_cast<const float4*>(ptab + 2 * NF + ch), is = *reinterpret_cast<const float4*>(ptab + 3 * NF + ch);
+                const float g4[4] = {ga.x, ga.y, ga.z, ga.w}, q4[4] = {p1.x, p1.y, p1.z, p1.w}, m4[4] = {mu.x, mu.y, mu.z, mu.w}, i4[4] = {is.x, is.y, is.z, is.w};
+                const float4 xa4 = *reinterpret_cast<const float4*>(Pf.X + go);
+                const float4 xb4 = Pf.S ? *reinterpret_cast<const float4*>(Pf.S + go) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float xa[4] = {xa4.x, xa4.y, xa4.z, xa4.w}, xb[4] = {xb4.x, xb4.y, xb4.z, xb4.w};
+                float o[4];
+                uint2 hi, lo;
+                if constexpr (PRO == 1) {   // t_bn_apply<false>
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float v = g4[j] * ((xa[j] - m4[j]) * i4[j]) + q4[j] + xb[j];
+                        o[j] = v > 0.0f ? v : 0.0f;
+                    }
+                    _Float16 h[4], l[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { h[j] = (_Float16)o[j]; l[j] = (_Float16)(o[j] - (float)h[j]); }
+                    hi = make_uint2(__builtin_bit_cast(uint32_t, f16x2_t{h[0], h[1]}), __builtin_bit_cast(uint32_t, f16x2_t{h[2], h[3]}));
+                    lo = make_uint2(__builtin_bit_cast(uint32_t, f16x2_t{l[0], l[1]}), __builtin_bit_cast(uint32_t, f16x2_t{l[2], l[3]}));
+                    if (cq == 0) {
+                        *reinterpret_cast<float4*>(Pf.O + go) = make_float4(o[0], o[1], o[2], o[3]);
+                        split_store4(o, go / 4, Pf.p0, Pf.p1, nullptr);
+                    }
+                } else {                    // t_bn_bwd_apply<false>
+                    const float4 s1 = *reinterpret_cast<const float4*>(ptab + 4 * NF + ch);
+                    const float t4[4] = {s1.x, s1.y, s1.z, s1.w};
+                    const float4 xc4 = *reinterpret_cast<const float4*>(Pf.Y + go);
+                    const float xc[4] = {xc4.x, xc4.y, xc4.z, xc4.w};
+                    float z[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const float dz = xb[j] > 0.0f ? xa[j] : 0.0f;
+                        const float xh = (xc[j] - m4[j]) * i4[j];
+                        z[j] = dz;
+                        o[j] = g4[j] * i4[j] * (dz - q4[j] - xh * t4[j]);
+                    }
+                    uint32_t h[4], m[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        h[j] = bf_rne_bits(o[j]);
+                        m[j] = bf_rne_bits(o[j] - __uint_as_float(h[j] << 16));
+                    }
+                    hi = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                    lo = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+                    if (cq == 0) {
+                        reinterpret_cast<uint2*>(Pf.p0)[go / 4] = hi;
+                        reinterpret_cast<uint2*>(Pf.p1)[go / 4] = lo;
+                        if (Pf.O) *reinterpret_cast<float4*>(Pf.O + go) = make_float4(z[0], z[1], z[2], z[3]);
+                    }
+                }
+                *reinterpret_cast<uint2*>(dst + r * CHB + seg * 8) = hi;
+                *reinterpret_cast<uint2*>(dst + PB + r * CHB + seg * 8) = lo;
+            }
+        }
+    }
+    asm volatile("" ::: "memory");   // (a wave's LDS operations execute in program order: its fragment reads follow its own stores)
+
+    // per lane: byte offset of its fragment row for (loop tap, tile) inside a part of a slice
+    uint32_t arow[9][MT];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) arow[t][mt] = (uint32_t)taprow[(AMODE == 2 ? 8 - t : t) * ZR + mt * 16 + c] * CHB + g * 16;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s16x8 a[MT][NP];
+#pragma unroll
+    for (int s2 = 0; s2 < 18; s2++) {
+        const int sl = s2 / 9, t = s2 % 9, cur = s2 % RING, ref = (s2 + RING - 1) % RING;
+        const uint8_t* bufc = wimg + sl * NP * PB;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int q = 0; q < NP; q++) a[mt][q] = *reinterpret_cast<const s16x8*>(bufc + q * PB + arow[t][mt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                const int qa = RsPass<2>::QA[p], qb = RsPass<2>::QB[p];
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    if constexpr (F16)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, bq[cur][qb][nt]), __builtin_bit_cast(f16x8_t, a[mt][qa]), acc[mt][nt], 0, 0, 0);
+                    else
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[cur][qb][nt]), __builtin_bit_cast(bf16x8, a[mt][qa]), acc[mt][nt], 0, 0, 0);
+                }
+                // one refill load of the ring slot the previous k-step freed per pass (8 loads over the 9 passes of a k-step)
+                const int slot = mt * 3 + p;
+                if (slot < NP * NT && s2 + RING - 1 < 18)
+                    bq[ref][slot / NT][slot % NT] = __builtin_amdgcn_raw_buffer_load_b128(wsrc[slot / NT], loff + (slot % NT) * 1024, (int)kstep_off(s2 + RING - 1), 0);
+            }
+        }
+    }
+
+    // ---- the four waves' partial sums meet in LDS (over the slices: every wave is done reading), added in wave order
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(img);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) red[((wave * MT + mt) * NT + nt) * 64 + lane] = acc[mt][nt];
+    __syncthreads();
+    f32x4 out[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        out[mt] = red[((0 * MT + mt) * NT + wave) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; w++) out[mt] += red[((w * MT + mt) * NT + wave) * 64 + lane];
+        if constexpr (F16) out[mt] *= oscale;
+    }
+    // wave w holds column tile w: lane (c, g) = cell mt * 16 + c, channels cq * 64 + wave * 16 + g * 4 ..
+    const int ch0 = cq * 64 + wave * 16 + g * 4;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, sx[4] = {0.0, 0.0, 0.0, 0.0};
+    float4 mu4 = make_float4(0.f, 0.f, 0.f, 0.f), is4 = mu4;
+    if constexpr (FUSE == 1) { mu4 = *reinterpret_cast<const float4*>(F.mean + ch0); is4 = *reinterpret_cast<const float4*>(F.istd + ch0); }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        const int r = mt * 16 + c;
+        if (r >= ROWS) continue;
+        const size_t o = (size_t)(m0 + r) * NF + ch0;
+        float4 v = make_float4(out[mt][0], out[mt][1], out[mt][2], out[mt][3]);
+        if constexpr (FUSE == 1) {
+            if (F.DS) {
+                const float4 d = *reinterpret_cast<const float4*>(F.DS + o);
+                v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+            }
+        }
+        *reinterpret_cast<float4*>(C + o) = v;
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        if constexpr (FUSE == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const double d = (double)vv[e]; s[e] += d; sx[e] += d * d; }
+        } else if constexpr (FUSE == 1) {
+            const float4 a4 = *reinterpret_cast<const float4*>(F.Apost + o), y4 = *reinterpret_cast<const float4*>(F.Y + o);
+            const float aa[4] = {a4.x, a4.y, a4.z, a4.w}, yy[4] = {y4.x, y4.y, y4.z, y4.w};
+            const float mm[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, ii[4] = {is4.x, is4.y, is4.z, is4.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float dz = aa[e] > 0.0f ? vv[e] : 0.0f;
+                s[e] += (double)dz;
+                sx[e] += (double)dz * (double)((yy[e] - mm[e]) * ii[e]);
+            }
+        }
+    }
+    if constexpr (FUSE != 0) {   // per-channel partials of this board: cells of a lane, then the 16 lanes of a channel group
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+#pragma unroll
+            for (int sft = 1; sft < 16; sft <<= 1) {
+                s[e] += __shfl_xor(s[e], sft);
+                sx[e] += __shfl_xor(sx[e], sft);
+            }
+            if (c == 0) {
+                F.part[((size_t)board * 2 + 0) * NF + ch0 + e] = s[e];
+                F.part[((size_t)board * 2 + 1) * NF + ch0 + e] = sx[e];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // t_wgrad_rs: the weight gradient  dW[tap][ci][co] = sum over rows of A[row + tap][ci] * dY[row][co]  (split bf16, 3 passes).
 // The reduction runs over ROWS, the slow index of both operands ([row][channel] in memory): the MFMA wants 8 consecutive
 // rows of one channel per lane.  gfx950's transposed LDS read (ds_read_b64_tr_b16) delivers exactly that from row-major
@@ -1102,7 +1364,8 @@ __global__ __launch_bounds__(64, 1) void t_wgrad_rs(Parts A, Parts G, float* __r
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
     const int slice = blockIdx.x % NS, rest = blockIdx.x / NS, cit = rest & 15, wq = rest >> 4;   // wq = which 64 co columns
     const int rbeg = slice * rows_per_slice, rend = min(M, rbeg + rows_per_slice);
-    const int nks = (rend - rbeg) / Wg::KR;    // whole k-steps: slices are multiples of 16 boards = 21 k-steps
+    const int nks = (rend - rbeg + Wg::KR - 1) / Wg::KR;   // k-steps; a slice that is not a multiple of 32 rows (8 boards = 10.5 k-steps) ends
+                                                          // inside one: the dY rows past the slice read as zero (range of gsrc below)
 
     // zero rows of the two A parts
     if (lane < 2 * (Wg::AST / 4))
@@ -1111,8 +1374,8 @@ __global__ __launch_bounds__(64, 1) void t_wgrad_rs(Parts A, Parts G, float* __r
     // staging units of this lane: 8 of the dY tile (4 (row, 16-byte segment) pairs x 2 parts: always inside the slice) and
     // up to 4 of the A tile (2 per part; halo rows before row 0 or after row M - 1 are out of range of the buffer resource
     // and read as 0).  Buffer loads: the k-step advances a scalar offset.
-    const __amdgpu_buffer_rsrc_t gsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(G.p[0]), (short)0, M * NF * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t gsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(G.p[1]), (short)0, M * NF * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(G.p[0]), (short)0, rend * NF * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(G.p[1]), (short)0, rend * NF * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t asrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A.p[0]), (short)0, M * NF * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t asrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A.p[1]), (short)0, M * NF * 2, 0x00020000);
     uint32_t goffs[4], gl[4], aoffs[2], al[2];
@@ -1873,6 +2136,7 @@ bool g_conv_rs = true;
 bool g_fwd_f16 = true;
 constexpr float FWD_WSCALE = 1024.0f;   // the packed forward kernels are 2^10 * W: |w| < 64 stays inside fp16, a weight of 1e-4 keeps a normal low part
 bool g_fuse_bwd = true;
+bool g_conv_q = true;       // t_conv_q for batches of up to 128 records (AZR_TRAIN_CONVQ=0: t_conv_rs at every size)
 bool g_fuse_apply = true;   // t_conv_rs<.., PRO>: the normalise kernels (t_bn_apply / t_bn_bwd_apply) computed in the consuming conv's staging path (AZR_TRAIN_FUSE_APPLY=0: separate kernels; same bits)   // t_conv_rs<2, 2, 1>: shortcut add + BN-backward stage 1 in the backward-data conv's epilogue (AZR_TRAIN_FUSE=0: separate kernels)
 
 struct TrainCtx {
@@ -1899,6 +2163,7 @@ struct TrainCtx {
     int world = 1, rank = 0;
     azr_allreduce_fn ar = nullptr;
     void* ar_ctx = nullptr;
+    bool native = false;       // the sums go through the handle's own RCCL communicator, in stream order (azr_dp_init)
     double* red = nullptr;     // [2 * NG][256] reduced BN partials
     double* hsum = nullptr;    // [6] head BN sums
     float* lr = nullptr;   // device: this step's bias-corrected learning rate
@@ -1951,6 +2216,7 @@ int ctx_ensure(azr_engine* h, int BS)
     g_fuse_bwd = !(getenv("AZR_TRAIN_FUSE") && atoi(getenv("AZR_TRAIN_FUSE")) == 0);
     g_fwd_f16 = !(getenv("AZR_TRAIN_FWD") && strcmp(getenv("AZR_TRAIN_FWD"), "bf16") == 0);
     g_fuse_apply = !(getenv("AZR_TRAIN_FUSE_APPLY") && atoi(getenv("AZR_TRAIN_FUSE_APPLY")) == 0);
+    g_conv_q = !(getenv("AZR_TRAIN_CONVQ") && atoi(getenv("AZR_TRAIN_CONVQ")) == 0);
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(t_wgrad_rs), hipFuncAttributeMaxDynamicSharedMemorySize, Wg::LDS_BYTES));
     // a different batch size rebuilds the activation slabs but keeps the optimiser state
     std::vector<float> keep_m, keep_v;
@@ -1985,7 +2251,8 @@ int ctx_ensure(azr_engine* h, int BS)
     TRY(dalloc(h, c, &c->part, (size_t)c->R * 2 * NG * NF));
     // t_wgrad_rs: slices of 16 j boards (16 boards = 672 rows = 21 k-steps), about 256 blocks = 16 ci tiles x slices
     {
-        const int bps = 16 * std::max(1, BS / 256);
+        // (small batches — a rank's share of a data-parallel minibatch: 8-board slices, so that 64 records are 512 one-wave blocks)
+        const int bps = (BS <= 128 && BS % 8 == 0) ? 8 : 16 * std::max(1, BS / 256);
         c->wg_slices = (BS + bps - 1) / bps;
         c->wg_rows = bps * NPOS;
     }
@@ -2058,11 +2325,52 @@ void gemm_sb(hipStream_t st, Parts A, int lda, Parts B, int ldb, float* C, int l
 
 inline dim3 grid1(size_t n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
-// one all-reduce (sum, in place) of a device buffer over the ranks of a data-parallel step, through the caller's callback
-// (RCCL over xGMI via torch.distributed on the GPU box).  The engine's stream is drained first: the callback runs on the
-// communicator's own stream and returns when the result is in place.
+// RCCL, bound at run time: dlopen("librccl.so.1") returns the copy a host process has already loaded (PyTorch-ROCm ships one under
+// the same soname) or /opt/rocm's — one RCCL, one HIP runtime per process, and libazr_hip.so itself carries no link dependency.
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+RcclApi* rccl_api()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return &api;
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (api.lib) break;
+    }
+    if (!api.lib) { api.err = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return &api; }
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.lib, "ncclAllReduce"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.GetErrorString) {
+        api.err = "RCCL: a symbol is missing from the loaded library";
+        api.lib = nullptr;
+    }
+    return &api;
+}
+
+// one all-reduce (sum, in place) of a device buffer over the ranks of a data-parallel step.  Native (azr_dp_init): ncclAllReduce on
+// the engine's own stream — stream-ordered, the host never waits (86 of them per step at B = 20: with a host hand-over each they
+// cost more than the step's kernels).  Otherwise through the caller's callback (a torch.distributed rehearsal over gloo, or any other
+// transport): the engine's stream is drained first, the callback returns when the result is in place.
 int dp_allreduce(azr_engine* h, TrainCtx* c, void* dev, size_t count, int dtype)
 {
+    if (c->native) {
+        RcclApi* R = rccl_api();
+        const ncclResult_t rc = R->AllReduce(dev, dev, count, dtype ? ncclDouble : ncclFloat, ncclSum, static_cast<ncclComm_t>(h->dp_comm), h->stream);
+        if (rc != ncclSuccess) { h->err = std::string("ncclAllReduce: ") + R->GetErrorString(rc); return AZR_E_HIP; }
+        return AZR_OK;
+    }
     if (!c->ar) return AZR_OK;
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2078,7 +2386,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     const int M = c->M, B = c->blocks, R = c->R, BS = c->BS;
     // data-parallel: BS / M are this rank's shard, BSg / Mg the whole minibatch every statistic and mean refers to
     const int W = c->world, BSg = BS * W, Mg = M * W;
-    const bool dp = c->ar != nullptr;   // a callback was supplied: the data-parallel code path, also with one rank (every sum is then the identity)
+    const bool dp = c->ar != nullptr || c->native;   // the data-parallel code path (a callback was supplied, or the handle has a communicator), also with one rank
     const float gscale = 1.0f / (float)W;
     // sums over the batch: [local partials -> one slab] -> all-reduce over the ranks -> the finalize kernel reads the slab
     auto reduce_parts = [&](int K) -> int {
@@ -2098,6 +2406,8 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     const unsigned g4 = (unsigned)((act / 4 + 255) / 256);
     const bool sb = g_gemm_bf16x3 && M % K3 == 0;  // split-bf16 conv GEMMs (the stem, K = 144, stays on the fp32 MFMA)
     const bool f16 = sb && g_conv_rs && g_fwd_f16; // forward conv: fp16 pairs, 3 passes
+    // small batches (a rank's share of a data-parallel minibatch): one board x 64 channels per block (t_conv_q) instead of 2 boards x 256
+    const bool convq = f16 && g_fuse_bwd && g_fuse_apply && g_conv_q && BS <= 128;
     auto Wpf = [&](int l) { const size_t o = (size_t)(l - 1) * KC * NF; return Parts{{c->wpf[0] + o, c->wpf[1] + o, c->wpf[2] + o}}; };
     auto Wpb = [&](int l) { const size_t o = (size_t)(l - 1) * KC * NF; return Parts{{c->wpb[0] + o, c->wpb[1] + o, nullptr}}; };
     if (sb) {
@@ -2130,12 +2440,21 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         int fwd_parts = 0;
         if (sb) {  // conv = implicit im2col x W in split precision (fp32-exact products)
             if (fap && l >= 2) {   // operand computed on the way in (layer l - 1's normalise step), statistics of the output on the way out
-                fwd_parts = (BS + 1) / 2;
                 const int m = l - 1;
-                hipLaunchKernelGGL((t_conv_rs<1, 2, 2, true, 1>), dim3(fwd_parts), dim3(256), 0, st, Parts{{nullptr, nullptr, nullptr}}, Wpf(l), Yl(l), BS,
-                                   BwdFuse{nullptr, nullptr, nullptr, nullptr, nullptr, c->part}, 1.0f / FWD_WSCALE,
-                                   ProFuse{Yl(m), (m % 2 == 0) ? (const float*)Al(m - 2) : (const float*)nullptr, nullptr, c->mean + m * NF, c->istd + m * NF,
-                                           Wl(m) + (size_t)9 * NF * NF, nullptr, 0.0f, Al(m), const_cast<uint16_t*>(Ap(m).p[0]), const_cast<uint16_t*>(Ap(m).p[1])});
+                const BwdFuse bf{nullptr, nullptr, nullptr, nullptr, nullptr, c->part};
+                const ProFuse pf{Yl(m), (m % 2 == 0) ? (const float*)Al(m - 2) : (const float*)nullptr, nullptr, c->mean + m * NF, c->istd + m * NF,
+                                 Wl(m) + (size_t)9 * NF * NF, nullptr, 0.0f, Al(m), const_cast<uint16_t*>(Ap(m).p[0]), const_cast<uint16_t*>(Ap(m).p[1])};
+                if (convq) {
+                    fwd_parts = BS;
+                    hipLaunchKernelGGL((t_conv_q<1, 2, true, 1>), dim3(4 * BS), dim3(256), 0, st, Parts{{nullptr, nullptr, nullptr}}, Wpf(l), Yl(l), BS, bf, 1.0f / FWD_WSCALE, pf);
+                } else {
+                    fwd_parts = (BS + 1) / 2;
+                    hipLaunchKernelGGL((t_conv_rs<1, 2, 2, true, 1>), dim3(fwd_parts), dim3(256), 0, st, Parts{{nullptr, nullptr, nullptr}}, Wpf(l), Yl(l), BS, bf, 1.0f / FWD_WSCALE, pf);
+                }
+            } else if (convq) {    // (layer 1: the stem's normalise kernel wrote the fp16 pair)
+                fwd_parts = BS;
+                hipLaunchKernelGGL((t_conv_q<1, 2, true, 0>), dim3(4 * BS), dim3(256), 0, st, Parts{{c->af[0], c->af[1], nullptr}}, Wpf(l), Yl(l), BS,
+                                   BwdFuse{nullptr, nullptr, nullptr, nullptr, nullptr, c->part}, 1.0f / FWD_WSCALE, ProFuse{});
             } else if (f16 && g_fuse_bwd) {   // + the batch statistics of the output, per block of 2 boards
                 fwd_parts = (BS + 1) / 2;
                 hipLaunchKernelGGL((t_conv_rs<1, 2, 2, true>), dim3(fwd_parts), dim3(256), 0, st, Parts{{c->af[0], c->af[1], nullptr}}, Wpf(l), Yl(l), BS,
@@ -2205,13 +2524,19 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
             // weight-gradient GEMM reads the parts it left behind
             const ProFuse pf{dOut, Al(l), Yl(l), c->mean + l * NF, c->istd + l * NF, bn, c->sums, invM, second ? c->DS : (float*)nullptr, c->dyp[0], c->dyp[1]};
             fused_parts = 0;
+            const Parts none{{nullptr, nullptr, nullptr}};
             if (l >= 2) {
-                fused_parts = (BS + 1) / 2;
-                hipLaunchKernelGGL((t_conv_rs<2, 2, 1, false, 2>), dim3(fused_parts), dim3(256), 0, st, Parts{{nullptr, nullptr, nullptr}}, Wpb(l), dIn, BS,
-                                   BwdFuse{second ? (const float*)nullptr : (const float*)c->DS, Al(l - 1), Yl(l - 1), c->mean + (l - 1) * NF,
-                                           c->istd + (l - 1) * NF, c->part}, 1.0f, pf);
+                const BwdFuse bf{second ? (const float*)nullptr : (const float*)c->DS, Al(l - 1), Yl(l - 1), c->mean + (l - 1) * NF, c->istd + (l - 1) * NF, c->part};
+                if (convq) {
+                    fused_parts = BS;
+                    hipLaunchKernelGGL((t_conv_q<2, 1, false, 2>), dim3(4 * BS), dim3(256), 0, st, none, Wpb(l), dIn, BS, bf, 1.0f, pf);
+                } else {
+                    fused_parts = (BS + 1) / 2;
+                    hipLaunchKernelGGL((t_conv_rs<2, 2, 1, false, 2>), dim3(fused_parts), dim3(256), 0, st, none, Wpb(l), dIn, BS, bf, 1.0f, pf);
+                }
             } else {
-                hipLaunchKernelGGL((t_conv_rs<2, 2, 0, false, 2>), dim3((BS + 1) / 2), dim3(256), 0, st, Parts{{nullptr, nullptr, nullptr}}, Wpb(l), dIn, BS, BwdFuse{}, 1.0f, pf);
+                if (convq) hipLaunchKernelGGL((t_conv_q<2, 0, false, 2>), dim3(4 * BS), dim3(256), 0, st, none, Wpb(l), dIn, BS, BwdFuse{}, 1.0f, pf);
+                else hipLaunchKernelGGL((t_conv_rs<2, 2, 0, false, 2>), dim3((BS + 1) / 2), dim3(256), 0, st, none, Wpb(l), dIn, BS, BwdFuse{}, 1.0f, pf);
                 if (!second) hipLaunchKernelGGL(t_add, dim3(g4), dim3(256), 0, st, dIn, c->DS, act / 4);
             }
             hipLaunchKernelGGL(t_wgrad_rs, dim3(64 * c->wg_slices), dim3(64), Wg::LDS_BYTES, st, apP, dyP, c->wpart, M, c->wg_slices, c->wg_rows);
@@ -2270,7 +2595,7 @@ int run_step(azr_engine* h, TrainCtx* c)
 {
     static const bool use_graph = getenv("AZR_TRAIN_GRAPH") && atoi(getenv("AZR_TRAIN_GRAPH")) != 0;
     c->step++;
-    if (!use_graph || c->ar) {   // (host callbacks of the data-parallel step cannot be captured)
+    if (!use_graph || c->ar || c->native) {   // (host callbacks of the data-parallel step cannot be captured)
         hipLaunchKernelGGL(t_gather, dim3(c->BS), dim3(64), 0, h->stream, c->rec, c->perm, (const int*)c->cur, c->BS, c->in88, c->pit, c->zt);
         return train_step(h, c, c->loss + 2);
     }
@@ -2326,6 +2651,10 @@ void train_free(azr_engine* h)
     h->train = nullptr;
 }
 }  // namespace azr
+extern "C" int azr_dp_shutdown(azr_engine* h);
+namespace azr {
+void dp_free(azr_engine* h) { azr_dp_shutdown(h); }
+}  // namespace azr
 
 #define ENTER(h)                                 \
     if (!(h)) return AZR_E_BAD_HANDLE;           \
@@ -2338,7 +2667,7 @@ extern "C" int azr_nn_train_batch(azr_engine* h, const void* rec265_host, int n,
     if (!rec265_host || n < 2) { h->err = "azr_nn_train_batch: need a minibatch of at least 2 records"; return AZR_E_INVALID_ARGUMENT; }
     TRY(ctx_ensure(h, n));
     TrainCtx* c = ctx_of(h);
-    c->world = 1; c->rank = 0; c->ar = nullptr; c->ar_ctx = nullptr;   // (a data-parallel call that failed half-way must not linger)
+    c->world = 1; c->rank = 0; c->ar = nullptr; c->ar_ctx = nullptr; c->native = false;   // (a data-parallel call that failed half-way must not linger)
     TRY(upload_records(h, c, rec265_host, (size_t)n));
     std::vector<int> id(n);
     for (int i = 0; i < n; i++) id[i] = i;
@@ -2362,12 +2691,17 @@ extern "C" int azr_nn_train_batch(azr_engine* h, const void* rec265_host, int n,
 // rank holds ALL n records and the same shuffle stream; of each minibatch of batch_size records rank r takes the slice
 // [r * batch_size / world, (r + 1) * batch_size / world).
 static int train_impl(azr_engine* h, const void* rec265_host, size_t n, int epochs, int batch_size, uint32_t* shuffle_rng_state, int rank,
-                      int world, azr_allreduce_fn ar, void* ar_ctx, float* loss_pi_host, float* loss_v_host)
+                      int world, azr_allreduce_fn ar, void* ar_ctx, float* loss_pi_host, float* loss_v_host, bool dp_call = false)
 {
     if (!h->weights_set) { h->err = "azr_nn_train: no weights"; return AZR_E_STATE; }
     if (!rec265_host || epochs < 0 || batch_size < 2) { h->err = "azr_nn_train: bad arguments"; return AZR_E_INVALID_ARGUMENT; }
-    if (world < 1 || rank < 0 || rank >= world || (world > 1 && !ar) || batch_size % world != 0 || batch_size / world < 2) {
-        h->err = "azr_nn_train_dp: need 0 <= rank < world, an all-reduce callback, and batch_size a multiple of world with >= 2 records per rank";
+    // no callback: the handle's own communicator (azr_dp_init) carries the sums.  (AZR_DP_LOOPBACK=1, a timing aid: a ONE-rank
+    // communicator stands in for `world` ranks — rank 0's share of the step with every collective in the stream, sums stay local.)
+    static const bool loopback = getenv("AZR_DP_LOOPBACK") && atoi(getenv("AZR_DP_LOOPBACK")) != 0;
+    const bool native = dp_call && !ar && h->dp_comm && ((h->dp_world == world && h->dp_rank == rank) || (loopback && h->dp_world == 1 && rank == 0));
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && !ar && !native) || batch_size % world != 0 || batch_size / world < 2) {
+        h->err = "azr_nn_train_dp: need 0 <= rank < world, batch_size a multiple of world with >= 2 records per rank, and either an all-reduce "
+                 "callback or a communicator of exactly this rank / world (azr_dp_init)";
         return AZR_E_INVALID_ARGUMENT;
     }
     const int local_bs = batch_size / world;
@@ -2384,7 +2718,7 @@ static int train_impl(azr_engine* h, const void* rec265_host, size_t n, int epoc
     if (batches > 0 && epochs > 0) {
         TRY(ctx_ensure(h, local_bs));
         c = ctx_of(h);
-        c->world = world; c->rank = rank; c->ar = ar; c->ar_ctx = ar_ctx;
+        c->world = world; c->rank = rank; c->ar = ar; c->ar_ctx = ar_ctx; c->native = native;
         TRY(upload_records(h, c, rec265_host, n));
     }
     int rc = AZR_OK;
@@ -2407,7 +2741,7 @@ static int train_impl(azr_engine* h, const void* rec265_host, size_t n, int epoc
         if (loss_pi_host) loss_pi_host[e] = l[0];
         if (loss_v_host) loss_v_host[e] = l[1];
     }
-    if (c) { c->world = 1; c->rank = 0; c->ar = nullptr; c->ar_ctx = nullptr; }
+    if (c) { c->world = 1; c->rank = 0; c->ar = nullptr; c->ar_ctx = nullptr; c->native = false; }
     if (rc) return rc;
     if (shuffle_rng_state) {
         // minstd_rand0 has no state accessor; operator<< prints the state as decimal text
@@ -2430,7 +2764,50 @@ extern "C" int azr_nn_train_dp(azr_engine* h, const void* rec265_host, size_t n,
                                int rank, int world, azr_allreduce_fn allreduce, void* ctx, float* loss_pi_host, float* loss_v_host)
 {
     ENTER(h);
-    return train_impl(h, rec265_host, n, epochs, batch_size, shuffle_rng_state, rank, world, allreduce, ctx, loss_pi_host, loss_v_host);
+    return train_impl(h, rec265_host, n, epochs, batch_size, shuffle_rng_state, rank, world, allreduce, ctx, loss_pi_host, loss_v_host, true);
+}
+
+// ---- the handle's own RCCL communicator (one process per GPU; the unique id travels by whatever the launcher has: torch.distributed,
+//      MPI, a file) ----------------------------------------------------------------------------------------------------------------
+extern "C" int azr_dp_unique_id(void* id128)
+{
+    if (!id128) return AZR_E_INVALID_ARGUMENT;
+    RcclApi* R = rccl_api();
+    if (!R->lib) return AZR_E_STATE;
+    ncclUniqueId id;
+    if (R->GetUniqueId(&id) != ncclSuccess) return AZR_E_HIP;
+    static_assert(sizeof id == AZR_DP_ID_BYTES, "ncclUniqueId size");
+    memcpy(id128, &id, sizeof id);
+    return AZR_OK;
+}
+
+extern "C" int azr_dp_shutdown(azr_engine* h)
+{
+    if (!h) return AZR_E_BAD_HANDLE;
+    if (h->dp_comm) {
+        (void)hipSetDevice(h->cfg.device);
+        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        rccl_api()->CommDestroy(static_cast<ncclComm_t>(h->dp_comm));
+        h->dp_comm = nullptr;
+    }
+    h->dp_rank = 0; h->dp_world = 0;
+    return AZR_OK;
+}
+
+extern "C" int azr_dp_init(azr_engine* h, int rank, int world, const void* id128)
+{
+    ENTER(h);
+    if (!id128 || world < 1 || rank < 0 || rank >= world) { h->err = "azr_dp_init: need 0 <= rank < world and the 128-byte id of azr_dp_unique_id"; return AZR_E_INVALID_ARGUMENT; }
+    RcclApi* R = rccl_api();
+    if (!R->lib) { h->err = R->err; return AZR_E_STATE; }
+    azr_dp_shutdown(h);
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t rc = R->CommInitRank(&comm, world, id, rank);   // collective over the `world` processes; binds to the current device
+    if (rc != ncclSuccess) { h->err = std::string("ncclCommInitRank: ") + R->GetErrorString(rc); return AZR_E_HIP; }
+    h->dp_comm = comm; h->dp_rank = rank; h->dp_world = world;
+    return AZR_OK;
 }
 
 extern "C" int azr_nn_train_grads(azr_engine* h, float* flat_host, size_t count)

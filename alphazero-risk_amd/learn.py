@@ -153,6 +153,7 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
     records = load_training_samples("data/training_samples.bin")   # trainStorage.loadTrainingSamples(DEFAULT_SAMPLES)
     old_game_index = 0
     games_started = 0   # self-play games this rank has started in earlier iterations (its position in its seed stream)
+    dp_native_ready = False
     sink = "/dev/null" if rank else None
     imp_log = open(sink or "log/azr-improvement-log.txt", "a")
     bench_log = open(sink or "log/azr-benchmark-log.txt", "a")
@@ -190,20 +191,31 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
         # ---- trainGroup->train (alphazero_gpu_cluster.cpp:221-231)
         t0 = time.time()
         hist = []
-        # --dp -1 (default): data-parallel only when every rank still gets a full 512-record slice.  At the reference's
-        # BATCH_SIZE 512 a rank's share is 512 / world records: the conv kernels of the step are one round of blocks on the
-        # GPU either way (a block's serial work sets the time, not the number of blocks), so the step gets no shorter, and
-        # it gains 2B + 4 latency-bound all-reduces of batch statistics plus one of 95 MB: rank 0 trains, as the reference does.
+        # --dp -1 (default): data-parallel from 4 ranks on.  A rank's share of the reference's BATCH_SIZE 512 is then <= 128 records,
+        # which the small-batch conv kernels (t_conv_q: one board x 64 channels per block, 8-board weight-gradient slices) spread over
+        # the whole GPU: rank 0's 64-record share of an 8-rank step takes 4.2 ms of kernels against 11.1 ms for all 512 records on one
+        # GPU (tools/train_bench.py --dp-world 8), plus 2B + 6 small in-stream all-reduces and one of 95 MB.  With 2 ranks the 256-record
+        # share runs the large-batch kernels at ~6 ms and the all-reduces eat the rest: rank 0 trains, as the reference does.
         dp_flag = getattr(a, "dp", -1)
-        dp = dist is not None and a.bs % world == 0 and a.bs // world >= 2 and (dp_flag == 1 or (dp_flag < 0 and a.bs // world >= 512))
+        dp = dist is not None and a.bs % world == 0 and a.bs // world >= 2 and (dp_flag == 1 or (dp_flag < 0 and world >= 4 and a.bs // world >= 16 and (a.bs // world) % 16 == 0))
         if dp:
             # data-parallel optimiser step: every rank takes 1/world of each minibatch (same shuffle stream everywhere);
             # batch statistics, losses and the gradient vector are all-reduced (RCCL over xGMI), every rank takes the
             # same Adam step — no weight broadcast
-            hist, shuffle_state = new.train_dp(records, a.e, shard_mod.make_allreduce(dist, cdev != "cpu", a.device), rank, world,
-                                               batch_size=a.bs, rng_state=shuffle_state)
+            if cdev != "cpu" and not getattr(a, "dp_callback", 0):
+                # RCCL over xGMI on the engine's own stream: the engine gets a communicator of its own (once), every sum of the
+                # step is stream-ordered
+                if not dp_native_ready:
+                    shard_mod.native_dp_init(new, dist, rank, world, cdev)
+                    dp_native_ready = True
+                hist, shuffle_state = new.train_dp(records, a.e, None, rank, world, batch_size=a.bs, rng_state=shuffle_state)
+                how = "in-stream ncclAllReduce on the engine's own communicator"
+            else:
+                hist, shuffle_state = new.train_dp(records, a.e, shard_mod.make_allreduce(dist, cdev != "cpu", a.device), rank, world,
+                                                   batch_size=a.bs, rng_state=shuffle_state)
+                how = ("torch.distributed all_reduce on device buffers, backend " + dist.get_backend()) if cdev != "cpu" else "host copies (gloo rehearsal)"
             hist = [h for h in hist if not np.isnan(h[0])]
-            log(f"Data-parallel optimiser step: all-reduces on {'device buffers, backend ' + dist.get_backend() if cdev != 'cpu' else 'host copies (gloo rehearsal)'}")
+            log(f"Data-parallel optimiser step: {how}")
             if rank == 0:
                 nn_log.write(nn_training_line(hist)); nn_log.flush()
         else:
@@ -283,7 +295,10 @@ def main():
     ap.add_argument("--include-compare-samples", type=int, default=1)   # INCLUDE_COMPARE_GAMES_TRAIN_SAMPLES
     ap.add_argument("--dp", type=int, default=-1,
                     help="multi-rank runs: 1 = data-parallel optimiser step over all ranks, 0 = rank 0 trains and broadcasts "
-                         "(the reference's AlphaZeroNNGroup::train), -1 (default) = data-parallel when --bs / world >= 512")
+                         "(the reference's AlphaZeroNNGroup::train), -1 (default) = data-parallel from 4 ranks on")
+    ap.add_argument("--dp-callback", type=int, default=0,
+                    help="1 = the data-parallel step's sums go through torch.distributed (one host hand-over each) instead of the engine's own "
+                         "in-stream RCCL communicator")
     a = ap.parse_args()
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and not shard_mod.force_dist():

@@ -88,6 +88,24 @@ def broadcast_flat(flat, dist=None, src=0, device="cpu"):
     return t.cpu().numpy()
 
 
+def native_dp_init(eng, dist, rank, world, device):
+    """give `eng` its own RCCL communicator over the ranks of `dist` (azr_dp_init): rank 0 draws the id, torch.distributed carries
+    its 128 bytes to the others, then every rank joins.  Afterwards eng.train_dp(..., allreduce=None, ...) sums in stream order on
+    the engine's own stream — no host hand-over per all-reduce."""
+    import importlib
+
+    import torch
+
+    P = importlib.import_module("alphazero-risk_amd")
+    buf = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        buf = torch.frombuffer(bytearray(P.dp_unique_id()), dtype=torch.uint8).clone()
+    buf = buf.to(device)
+    if _active(dist) or (dist is not None and dist.is_initialized() and dist.get_world_size() > 1):
+        dist.broadcast(buf, src=0)
+    eng.dp_init(rank, world, bytes(buf.cpu().numpy().tobytes()))
+
+
 class _DevicePtr:
     """a raw device allocation seen through the CUDA array interface (torch.as_tensor aliases it, no copy)"""
 

@@ -127,11 +127,22 @@ int azr_nn_train(azr_engine* h, const void* rec265_host, size_t n, int epochs, i
  * (azr_nn_param_count floats) — is summed over the ranks through `allreduce`: in place on DEVICE memory of this GPU,
  * dtype 0 = float32, 1 = float64, return 0 on success; the engine's stream is idle while it runs.  All ranks then take the
  * same Adam step, so their weights stay equal without a broadcast, and equal the single-GPU step's up to summation
- * order.  world = 1 with allreduce == NULL is azr_nn_train; world = 1 WITH a callback runs the data-parallel code path on one
- * rank (every all-reduce is the identity): the single-GPU rehearsal of the RCCL path. */
+ * order.  world = 1 with allreduce == NULL and no communicator is azr_nn_train; world = 1 WITH a callback (or a one-rank
+ * communicator, azr_dp_init) runs the data-parallel code path on one rank (every all-reduce is the identity): the single-GPU
+ * rehearsal of the RCCL path.  allreduce == NULL with world > 1 needs azr_dp_init(h, rank, world, ...). */
 typedef int (*azr_allreduce_fn)(void* ctx, void* device_ptr, size_t count, int dtype);
 int azr_nn_train_dp(azr_engine* h, const void* rec265_host, size_t n, int epochs, int batch_size, uint32_t* shuffle_rng_state,
                     int rank, int world, azr_allreduce_fn allreduce, void* ctx, float* loss_pi_host, float* loss_v_host);
+/* The handle's own RCCL communicator for azr_nn_train_dp (one process per GPU, RCCL over xGMI).  With it — and allreduce == NULL —
+ * every sum of the data-parallel step is an ncclAllReduce on the engine's own stream: stream-ordered, no host hand-over (2B + 6
+ * small sums and one of azr_nn_param_count floats per step).  Rank 0 draws the 128-byte id (azr_dp_unique_id) and passes it to the
+ * other processes by whatever the launcher offers (torch.distributed broadcast, MPI, a file); then EVERY rank calls azr_dp_init
+ * (collective).  RCCL is bound at run time ("librccl.so.1": the copy already loaded into the process, else /opt/rocm's);
+ * AZR_E_STATE if there is none.  azr_engine_destroy shuts the communicator down. */
+#define AZR_DP_ID_BYTES 128
+int azr_dp_unique_id(void* id128);
+int azr_dp_init(azr_engine* h, int rank, int world, const void* id128);
+int azr_dp_shutdown(azr_engine* h);
 /* one `session->Run(..., {optimize})` (alphazero_nn.cpp:389-391) on exactly n records in the given order */
 int azr_nn_train_batch(azr_engine* h, const void* rec265_host, int n, float* loss_pi, float* loss_v);
 /* diagnostics: gradient vector of the last step in AZRW layout (moving-statistics slots unused) */

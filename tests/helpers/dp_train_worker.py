@@ -44,6 +44,7 @@ def main():
     rec[:, 93:265] = pi.view(np.uint8).reshape(n, 172)
 
     ar = shard.make_allreduce(dist, on_device=(backend == "nccl"), device_index=0)
+    native = os.environ.get("DP_NATIVE", "0") == "1"   # the engine's own RCCL communicator: every sum in stream order, no callback
     res = {}
     for tag, nn, ep in (("one", bs, 1), ("multi", n, epochs)):   # one single step (tight comparison), then 2 epochs x 3 steps
         eng = P.Engine(4, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64)
@@ -54,7 +55,9 @@ def main():
             calls.append((count, dtype))
             ar(ptr, count, dtype)
 
-        hist, state = eng.train_dp(rec[:nn], ep, counted, rank, world, batch_size=bs, rng_state=4321)
+        if native:
+            shard.native_dp_init(eng, dist, rank, world, torch.device("cuda", 0))
+        hist, state = eng.train_dp(rec[:nn], ep, None if native else counted, rank, world, batch_size=bs, rng_state=4321)
         w_dp, g_dp = eng.get_weights(), eng.train_grads()
         bad = 0
         try:   # a minibatch that does not split evenly over the ranks is refused

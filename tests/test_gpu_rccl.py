@@ -58,12 +58,12 @@ def test_learn_iteration_over_rccl_with_one_rank(tmp_path, dp):
     engine's own device buffers (--dp 1)"""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), os.path.join(ROOT, "alphazero-risk_amd", "learn.py"), "--ti", "1", "--tg", "8", "--mcts", "6",
-           "--gpu-games", "8", "--blocks", "1", "-e", "2", "--bs", "64", "--cg", "8", "--ct", "0", "--dp", dp]
+           "--gpu-games", "8", "--blocks", "1", "-e", "2", "--bs", "64", "--cg", "8", "--ct", "0", "--dp", dp, "--dp-callback", "1"]
     r = subprocess.run(cmd, cwd=tmp_path, env=_env(AZR_FORCE_DIST="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-2000:]
     assert "Record exchange: all_gather + counter all_reduce, backend nccl, tensors on cuda:0" in r.stdout
     if dp == "1":
-        assert "Data-parallel optimiser step: all-reduces on device buffers, backend nccl" in r.stdout
+        assert "Data-parallel optimiser step: torch.distributed all_reduce on device buffers, backend nccl" in r.stdout
     else:
         assert "Weight broadcast from rank 0: backend nccl, tensor on cuda:0" in r.stdout
     assert "Model improved" in r.stdout and "Loss Policy / Value" in r.stdout
@@ -112,3 +112,45 @@ def test_data_parallel_step_over_rccl_aliases_engine_buffers(tmp_path):
     rel = np.abs(d["multi_hist_dp"] - d["multi_hist_1"]) / np.abs(d["multi_hist_1"])
     assert rel.max() <= 1e-3
     print(f"RCCL, one rank: max rel grad diff {worst:.2e}, median |dw| {np.median(dw[moved]):.1e}, multi-step loss rel diff {rel.max():.1e}")
+
+
+def test_data_parallel_step_on_the_engines_own_rccl_communicator(tmp_path):
+    """azr_dp_init + azr_nn_train_dp(allreduce = NULL): the handle's own communicator (RCCL bound at run time), every sum an
+    ncclAllReduce on the engine's stream.  One rank (one GPU here): each sum is the identity, so the step equals the single-GPU step
+    like the callback form; the id travels through torch.distributed as in learn.py."""
+    blocks = 2
+    out = str(tmp_path / "dp.npz")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "tests", "helpers", "dp_train_worker.py"), out]
+    r = subprocess.run(cmd, env=_env(DP_BLOCKS=str(blocks), DP_BS="64", DP_N="200", DP_BACKEND="nccl", DP_NATIVE="1"), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-1000:]
+    d = np.load(out)
+    assert len(d["one_calls"]) == 0 and len(d["multi_calls"]) == 0     # no callback ran: the sums went through the communicator
+    assert int(d["one_state_dp"]) == int(d["one_state_1"])
+    assert np.abs(d["one_hist_dp"] - d["one_hist_1"]).max() <= 2e-5
+    worst = 0.0
+    for name, off, n in T.net_layout(blocks):
+        a, b = d["one_g_dp"][off:off + n], d["one_g_1"][off:off + n]
+        if name.endswith("_bn"):
+            a, b = a[:n // 2], b[:n // 2]
+        scale = np.abs(b).max()
+        if scale > 0:
+            worst = max(worst, np.abs(a - b).max() / scale)
+    assert worst <= 2e-3, worst
+    rel = np.abs(d["multi_hist_dp"] - d["multi_hist_1"]) / np.abs(d["multi_hist_1"])
+    assert rel.max() <= 1e-3
+    assert np.abs(d["multi_w_dp"] - d["w0"]).max() > 1e-3
+    print(f"native RCCL communicator, one rank: max rel grad diff {worst:.2e}, multi-step loss rel diff {rel.max():.1e}")
+
+
+def test_learn_iteration_with_the_native_communicator(tmp_path):
+    """learn.py --dp 1 on device tensors takes the engine's own communicator by default (the torch.distributed callback only with
+    --dp-callback 1)"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "alphazero-risk_amd", "learn.py"), "--ti", "1", "--tg", "8", "--mcts", "6",
+           "--gpu-games", "8", "--blocks", "1", "-e", "2", "--bs", "64", "--cg", "8", "--ct", "0", "--dp", "1"]
+    r = subprocess.run(cmd, cwd=tmp_path, env=_env(AZR_FORCE_DIST="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-2000:]
+    assert "Data-parallel optimiser step: in-stream ncclAllReduce on the engine's own communicator" in r.stdout
+    assert "Model improved" in r.stdout and "Loss Policy / Value" in r.stdout
