@@ -62,7 +62,6 @@ struct Bf16Net {
     uint16_t* stem_wp = nullptr;
     uint16_t* tower_wp = nullptr;
     unsigned long long* diag = nullptr;  // set only by azr_debug_tower_clock
-    int nt = 2;        // column tiles per wave of k_tower_bf16 (AZR_TOWER_NT, read once at creation)
     int sb_mode = 1;   // use of the single-image tiles: 0 never, 1 plan, 2 / 3 / 4 force 4 / 2 / 3 boards (AZR_TOWER_SB, read once at creation)
 };
 inline Bf16Net* bf16net(azr_engine* h) { return reinterpret_cast<Bf16Net*>(h->net.bf16ctx); }

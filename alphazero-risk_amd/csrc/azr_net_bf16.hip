@@ -567,13 +567,9 @@ int net_bf16_alloc(azr_engine* h)
     HIPCHK(h, hipMalloc((void**)&x->tower_wp, ((size_t)2 * B * TOWER_LAYER_HALFS + MAX_RING * KSTRIDE * 8) * 2));  // + ring run-off
     HIPCHK(h, hipMemsetAsync(x->tower_wp, 0, ((size_t)2 * B * TOWER_LAYER_HALFS + MAX_RING * KSTRIDE * 8) * 2, h->stream));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<1>::LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<2>::LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<3>::LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<1>::LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<2>::LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<3>::LDS_BYTES));
-    // tuning switches are read ONCE, here (never in the launch path)
-    x->nt = getenv("AZR_TOWER_NT") && atoi(getenv("AZR_TOWER_NT")) == 4 ? 4 : 2;
+    // test / measurement switch, read ONCE, here (never in the launch path): AZR_TOWER_SB = 0: the two-image kernel (one board per
+    // workgroup) for every launch — the independently written implementation the single-image tiles are compared with bit for bit;
+    // 1 (default): plan; 2 / 3 / 4: force the 4- / 2- / 3-board single-image tile
     x->sb_mode = getenv("AZR_TOWER_SB") ? atoi(getenv("AZR_TOWER_SB")) : 1;
     return tower_sb_init(h);
 }
@@ -633,14 +629,19 @@ static int plan_sb(int sb_mode, int n)
 {
     int snb = sb_mode == 2 ? 4 : sb_mode == 3 ? 2 : sb_mode == 4 ? 3 : 0;
     if (sb_mode == 1 && n > 256) {
-        // measured launch time of one 256-workgroup round, ms (tools/tower_time.py): 2 / 3 / 4 boards per workgroup.
-        // One workgroup per CU is resident, so a launch of w workgroups takes ceil(w / 256) rounds.
-        static const float T[5] = {0.0f, 0.0f, 0.61f, 0.80f, 1.05f};
+        // Relative time of one 256-workgroup round of 2 / 3 / 4 boards per workgroup.  One workgroup per CU is resident, so a launch
+        // of w workgroups takes ceil(w / 256) rounds, and only the RATIOS of the round times enter the choice: the three tiles are
+        // the same MFMA-bound code, so a box that clocks lower stretches all three alike.  The ratios are those of the tiles'
+        // measured shader cycles per workgroup (1.115 / 1.415 / 1.938 M cycles); launch times measured on three
+        // boxes of the pool (1.77 - 2.0 GHz sustained): 0.61 / 0.80 / 1.05 ms, 0.63 / 0.82 / 1.07 and 0.68 / 0.89 / 1.18 — the same
+        // ratios to 2 %, far inside the margins the plan turns on (the closest call, 768 boards: 3 x 256 at 0.73 against 2 rounds of
+        // 2-board tiles at 1.15).
+        static const float T[5] = {0.0f, 0.0f, 0.575f, 0.730f, 1.0f};
         float best = 0.0f;
         for (int c = 4; c >= 2; c--) {
             const int w = (n + c - 1) / c;
-            const float ms = (float)((w + 255) / 256) * T[c];
-            if (snb == 0 || ms < best) { snb = c; best = ms; }
+            const float t = (float)((w + 255) / 256) * T[c];
+            if (snb == 0 || t < best) { snb = c; best = t; }
         }
     }
     return n >= snb ? snb : 0;
@@ -652,28 +653,14 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
     const float* fold = net_fold(h);
     const int B = h->net.blocks;
     if (h->pe_tower0) hipEventRecord(h->pe_tower0, st);
-    // boards per workgroup: fill the 256 CUs first, then grow the M tile.  Wave tiling: 8 waves x 32 channels by
-    // default; AZR_TOWER_NT=4 selects the 4-wave x 64-channel shape (measured equal at NB = 1, 2; slower at NB = 3).
-    const int NT = x->nt;
-#define LAUNCH_TOWER(NBV, NTV)                                                                                      \
-    hipLaunchKernelGGL((k_tower_bf16<NBV, NTV>), dim3(wgs), dim3(1024 / NTV), Geo<NBV>::LDS_BYTES,                 \
-                       st, d_in88, in_stride, n, x->stem_wp, x->tower_wp, fold, B, net_head_params(h), d_pi, d_v, x->diag, n_full, d_map)
-    // One workgroup per CU is resident (LDS and VGPR budget), so the batch is cut into r rounds of 256 workgroups and
-    // the boards are dealt as evenly as 1..3 per workgroup allows: `n_full` workgroups of nb boards first, the rest nb - 1.
-    const int rounds = (n + 767) / 768, W = 256 * rounds;
-    int wgs = W, nb = n / W, n_full = n % W;
-    if (nb == 0) { nb = 1; wgs = n_full = n; }          // fewer boards than CUs: one each
-    else if (n_full == 0) n_full = W;                  // exact multiple: all workgroups carry nb
-    else nb += 1;
-    if (const int snb = plan_sb(x->sb_mode, n)) {
+    if (const int snb = plan_sb(x->sb_mode, n)) {   // more than 256 boards: 2, 3 or 4 per workgroup in one LDS image (azr_tower_sb.hip)
         int rc = tower_sb_launch(h, snb, (n + snb - 1) / snb, d_in88, in_stride, n, d_pi, d_v, d_map, st);
         if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
         return rc;
     }
-    if (nb == 1) { if (NT == 2) LAUNCH_TOWER(1, 2); else LAUNCH_TOWER(1, 4); }
-    else if (nb == 2) { if (NT == 2) LAUNCH_TOWER(2, 2); else LAUNCH_TOWER(2, 4); }
-    else { if (NT == 2) LAUNCH_TOWER(3, 2); else LAUNCH_TOWER(3, 4); }
-#undef LAUNCH_TOWER
+    // up to 256 boards (or AZR_TOWER_SB=0): one board per workgroup, two ping-pong images, 8 waves x 32 channels
+    hipLaunchKernelGGL((k_tower_bf16<1, 2>), dim3(n), dim3(512), Geo<1>::LDS_BYTES, st, d_in88, in_stride, n, x->stem_wp, x->tower_wp, fold, B,
+                       net_head_params(h), d_pi, d_v, x->diag, n, d_map);
     if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
     HIPCHK(h, hipGetLastError());
     return AZR_OK;
@@ -710,9 +697,8 @@ extern "C" int azr_debug_tower_plan(azr_engine* h, int n, int* boards_per_wg, in
     if (!h || !h->net.bf16ctx || n < 1) return AZR_E_STATE;
     const int snb = plan_sb(bn(h)->sb_mode, n);
     if (snb) { *boards_per_wg = snb; *wgs = (n + snb - 1) / snb; return AZR_OK; }
-    const int rounds = (n + 767) / 768, W = 256 * rounds;   // the mixed 1..3-board launch of net_bf16_forward
-    *wgs = n < W ? n : W;
-    *boards_per_wg = (n + W - 1) / W;
+    *wgs = n;   // one board per workgroup (k_tower_bf16<1>)
+    *boards_per_wg = 1;
     return AZR_OK;
 }
 

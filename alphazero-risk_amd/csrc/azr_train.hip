@@ -14,8 +14,8 @@
 // value is the exact sum of three bf16 parts; the forward multiplies all parts that matter (6 MFMA passes, fp32-exact
 // products, so ReLU masks and batch statistics are those of an fp32 forward), the two gradient GEMMs use two parts (3
 // passes, 1e-5 relative) — with t_gemm on the fp32 MFMA (v_mfma_f32_32x32x2_f32) kept for the stem (K = 144), odd
-// batch sizes and AZR_TRAIN_GEMM=f32.  Kernels of the split-bf16 path: t_conv_rs (forward, backward-data) and t_wgrad_rs
-// (weight gradient) by default; t_conv_sb / t_gemm_sb (the round-1 tiles) under AZR_TRAIN_GEMM=sb.
+// batch sizes and AZR_TRAIN_GEMM=f32.  Kernels of the split path: t_conv_rs / t_conv_q (forward on fp16 pairs, backward-data on two
+// bf16 parts, with the normalise and statistics steps fused into their staging paths and epilogues) and t_wgrad_rs (weight gradient).
 // Every conv output (pre-BN) and every post-activation is kept for the backward pass: 2 x 22 MB per layer at batch 512,
 // 1.8 GB for the 41 conv layers of B = 20 — sized for 288 GB of HBM, nothing is recomputed.
 // Reductions (BN statistics, bias / BN / head gradients, split-K) are two-stage and atomic-free: a step is
@@ -263,175 +263,6 @@ __device__ __forceinline__ void split_store4_f16(const float (&v)[4], size_t i4,
     reinterpret_cast<uint2*>(q1)[i4] = make_uint2(__builtin_bit_cast(uint32_t, f16x2_t{l[0], l[1]}), __builtin_bit_cast(uint32_t, f16x2_t{l[2], l[3]}));
 }
 
-// x[n] fp32 -> NP bf16 part arrays (n % 4 == 0)
-template <int NP>
-__global__ __launch_bounds__(256) void t_split(const float* __restrict__ x, size_t n4, uint16_t* __restrict__ p0, uint16_t* __restrict__ p1,
-                                               uint16_t* __restrict__ p2)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    const float4 v4 = reinterpret_cast<const float4*>(x)[i];
-    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
-    uint32_t h[4], m[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        h[j] = bf_rne_bits(v[j]);
-        const float r1 = v[j] - __uint_as_float(h[j] << 16);
-        m[j] = bf_rne_bits(r1);
-        if (NP == 3) l[j] = bf_rne_bits(r1 - __uint_as_float(m[j] << 16));
-    }
-    reinterpret_cast<uint2*>(p0)[i] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-    reinterpret_cast<uint2*>(p1)[i] = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
-    if (NP == 3) reinterpret_cast<uint2*>(p2)[i] = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
-}
-// k-contiguous operand (storage [mn][k]): T rows x 32 k per tile; T / 64 16-byte loads (8 bf16) per thread and part
-template <int T, int MODE, int NP>
-__device__ __forceinline__ void sb_load_kc(const Parts& P, int ld, int mn0, int k0, int MN, int Kend, int t, uint4 (&r)[NP][T / 64])
-{
-    constexpr int V = T / 8, TPR = 32 / V;
-    const int mn = mn0 + t / TPR, k = k0 + (t % TPR) * V;
-    size_t off;
-    bool ok;
-    if constexpr (MODE == 1 || MODE == 2) {
-        const int tap = k >> 8, c = k & 255;
-        int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        if (MODE == 2) { dy = -dy; dx = -dx; }
-        const int pos = mn % NPOS, y = pos / 6 + dy, x = pos - (pos / 6) * 6 + dx;
-        ok = mn < MN && k < Kend && y >= 0 && y < 7 && x >= 0 && x < 6;
-        off = (size_t)(mn + dy * 6 + dx) * NF + c;
-    } else if constexpr (MODE == 3) {
-        off = (size_t)(k >> 8) * (NF * NF) + (size_t)mn * NF + (k & 255);
-        ok = mn < MN && k < Kend;
-    } else {
-        off = (size_t)mn * ld + k;
-        ok = mn < MN && k < Kend;
-    }
-#pragma unroll
-    for (int q = 0; q < NP; q++)
-#pragma unroll
-        for (int u = 0; u < V / 8; u++)
-            r[q][u] = ok ? reinterpret_cast<const uint4*>(P.p[q] + off)[u] : make_uint4(0u, 0u, 0u, 0u);
-}
-template <int T, int NP>
-__device__ __forceinline__ void sb_store_kc(uint16_t* S, int part_stride, int t, const uint4 (&r)[NP][T / 64])
-{
-    constexpr int V = T / 8, TPR = 32 / V;
-    const int o = (t / TPR) * KP3 + (t % TPR) * V;
-#pragma unroll
-    for (int q = 0; q < NP; q++)
-#pragma unroll
-        for (int u = 0; u < V / 8; u++) reinterpret_cast<uint4*>(S + q * part_stride + o)[u] = r[q][u];
-}
-
-// mn-contiguous operand (storage [k][mn]), 128 wide: thread = (pair of columns, group of 8 k-rows)
-template <int MODE, int NP>
-__device__ __forceinline__ void sb_load_mc(const Parts& P, int ld, int mn0, int k0, int MN, int Kend, int t, uint32_t (&r)[NP][8])
-{
-    const int mn = mn0 + 2 * (t & 63), kb = k0 + (t >> 6) * 8;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int k = kb + i;
-        bool ok = k < Kend && mn + 1 < MN;
-        size_t off;
-        if constexpr (MODE == 1) {  // col^T: k = activation row, mn = tap * 256 + c
-            const int tap = mn >> 8, c = mn & 255;
-            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-            const int pos = k % NPOS, y = pos / 6 + dy, x = pos - (pos / 6) * 6 + dx;
-            ok = ok && y >= 0 && y < 7 && x >= 0 && x < 6;
-            off = (size_t)(k + dy * 6 + dx) * NF + c;
-        } else {
-            off = (size_t)k * ld + mn;
-        }
-#pragma unroll
-        for (int q = 0; q < NP; q++) r[q][i] = ok ? *reinterpret_cast<const uint32_t*>(P.p[q] + off) : 0u;
-    }
-}
-template <int NP>
-__device__ __forceinline__ void sb_store_mc(uint16_t* S, int part_stride, int t, const uint32_t (&r)[NP][8])
-{
-    const int row = 2 * (t & 63), kg = (t >> 6) * 8;
-#pragma unroll
-    for (int q = 0; q < NP; q++) {
-        uint4 c0, c1;  // the 8 k-values of the even / odd column
-        c0.x = __builtin_amdgcn_perm(r[q][1], r[q][0], 0x05040100u); c1.x = __builtin_amdgcn_perm(r[q][1], r[q][0], 0x07060302u);
-        c0.y = __builtin_amdgcn_perm(r[q][3], r[q][2], 0x05040100u); c1.y = __builtin_amdgcn_perm(r[q][3], r[q][2], 0x07060302u);
-        c0.z = __builtin_amdgcn_perm(r[q][5], r[q][4], 0x05040100u); c1.z = __builtin_amdgcn_perm(r[q][5], r[q][4], 0x07060302u);
-        c0.w = __builtin_amdgcn_perm(r[q][7], r[q][6], 0x05040100u); c1.w = __builtin_amdgcn_perm(r[q][7], r[q][6], 0x07060302u);
-        *reinterpret_cast<uint4*>(S + q * part_stride + row * KP3 + kg) = c0;
-        *reinterpret_cast<uint4*>(S + q * part_stride + (row + 1) * KP3 + kg) = c1;
-    }
-}
-
-template <bool A_MCONTIG, bool B_KCONTIG, int BM, int AMODE, int BMODE, int NP>
-__global__ __launch_bounds__(256) void t_gemm_sb(Parts A, int lda, Parts B, int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
-                                                 int kchunk, size_t strideCz)
-{
-    static_assert(!A_MCONTIG || BM == 128, "the mn-contiguous loader is 128 wide");
-    constexpr int MI = BM / 32;  // 16-row MFMA tiles per wave along m
-    constexpr int SA = BM * KP3, SB = GT * KP3;
-    __shared__ __attribute__((aligned(16))) uint16_t As[NP * SA];
-    __shared__ __attribute__((aligned(16))) uint16_t Bs[NP * SB];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * GT;
-    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
-    f32x4 acc[MI][4];
-#pragma unroll
-    for (int i = 0; i < MI; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    uint4 rak[NP][BM / 64], rbk[NP][GT / 64];
-    uint32_t ram[NP][8], rbm[NP][8];
-    auto loadA = [&](int k0) {
-        if constexpr (A_MCONTIG) sb_load_mc<AMODE, NP>(A, lda, m0, k0, M, kend, t, ram);
-        else sb_load_kc<BM, AMODE, NP>(A, lda, m0, k0, M, kend, t, rak);
-    };
-    auto loadB = [&](int k0) {
-        if constexpr (B_KCONTIG) sb_load_kc<GT, BMODE, NP>(B, ldb, n0, k0, N, kend, t, rbk);
-        else sb_load_mc<BMODE, NP>(B, ldb, n0, k0, N, kend, t, rbm);
-    };
-    loadA(kbeg);
-    loadB(kbeg);
-    const int fo = (lane & 15) * KP3 + (lane >> 4) * 8;  // this lane's fragment offset inside a 16-row tile
-    for (int k0 = kbeg; k0 < kend; k0 += K3) {
-        __syncthreads();
-        if constexpr (A_MCONTIG) sb_store_mc<NP>(As, SA, t, ram); else sb_store_kc<BM, NP>(As, SA, t, rak);
-        if constexpr (B_KCONTIG) sb_store_kc<GT, NP>(Bs, SB, t, rbk); else sb_store_mc<NP>(Bs, SB, t, rbm);
-        __syncthreads();
-        if (k0 + K3 < kend) { loadA(k0 + K3); loadB(k0 + K3); }
-        s16x8 b[NP][4];
-#pragma unroll
-        for (int q = 0; q < NP; q++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) b[q][j] = *reinterpret_cast<const s16x8*>(Bs + q * SB + (wn * 64 + j * 16) * KP3 + fo);
-        s16x8 a[NP][MI];
-#pragma unroll
-        for (int q = 0; q < NP; q++)
-#pragma unroll
-            for (int i = 0; i < MI; i++) a[q][i] = *reinterpret_cast<const s16x8*>(As + q * SA + (wm * (BM / 2) + i * 16) * KP3 + fo);
-        // part pairs outermost (smallest terms first): back-to-back MFMAs then write DIFFERENT accumulators — a chain of
-        // dependent MFMAs on one accumulator would leave the matrix pipe idle for most of each instruction's latency
-#define SB_PASS(qa, qb)                                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < MI; i++) _Pragma("unroll") for (int j = 0; j < 4; j++)                          \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[qa][i]), __builtin_bit_cast(bf16x8, b[qb][j]), acc[i][j], 0, 0, 0)
-        if constexpr (NP == 3) { SB_PASS(2, 0); SB_PASS(0, 2); SB_PASS(1, 1); }
-        SB_PASS(1, 0);
-        SB_PASS(0, 1);
-        SB_PASS(0, 0);
-#undef SB_PASS
-    }
-    float* Cz = C + (size_t)blockIdx.z * strideCz;
-#pragma unroll
-    for (int i = 0; i < MI; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int row = m0 + wm * (BM / 2) + i * 16 + 4 * (lane >> 4) + e;
-                const int col = n0 + wn * 64 + j * 16 + (lane & 15);
-                if (row < M && col < N) Cz[(size_t)row * ldc + col] = acc[i][j][e];
-            }
-}
-
 // =====================================================================================================================
 // Conv GEMMs whose B operand is the layer's kernel (forward, backward-data): N = 256, K = 2304.  The measured limit of
 // t_gemm_sb on these shapes is LDS traffic, two thirds of it the weight tile.  Here the weights never touch LDS: t_pack_w
@@ -477,85 +308,6 @@ __global__ __launch_bounds__(256) void t_pack_w(const float* __restrict__ flat, 
     reinterpret_cast<uint4*>(p0)[o] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
     reinterpret_cast<uint4*>(p1)[o] = make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
     if (NP == 3) reinterpret_cast<uint4*>(p2)[o] = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
-}
-
-// C[M][256] = im2col(A) x B.  AMODE 1 (forward taps) / 2 (negated taps); A = bf16 parts of an activation [M][256];
-// Bp = packed parts of this layer's kernel in the matching view.  One block iteration covers KS MFMA k-steps (KS * 32 of
-// K) between two barriers (KS = 2 measured within 2 % of KS = 1, which is used).
-template <int AMODE, int NP, int KS>
-__global__ __launch_bounds__(256) void t_conv_sb(Parts A, Parts Bp, float* __restrict__ C, int M)
-{
-    constexpr int BM = 64, LDK = KS * K3 + 8, SA = BM * LDK, KT = KC / (KS * K3);
-    __shared__ __attribute__((aligned(16))) uint16_t As[NP * SA];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int m0 = blockIdx.y * BM, nt0 = blockIdx.x * 8 + wave * 2;  // this wave's two 16-column tiles
-    f32x4 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    uint4 ra[KS][NP][1];
-    uint4 rb[KS][NP][2];
-    auto loadA = [&](int kt) {
-#pragma unroll
-        for (int s2 = 0; s2 < KS; s2++) sb_load_kc<BM, AMODE, NP>(A, 0, m0, (kt * KS + s2) * K3, M, KC, t, ra[s2]);
-    };
-    auto loadB = [&](int kt) {
-#pragma unroll
-        for (int s2 = 0; s2 < KS; s2++)
-#pragma unroll
-            for (int q = 0; q < NP; q++)
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-                    rb[s2][q][j] = reinterpret_cast<const uint4*>(Bp.p[q])[((size_t)(kt * KS + s2) * 16 + nt0 + j) * 64 + lane];
-    };
-    loadA(0);
-    loadB(0);
-    const int so = (t >> 2) * LDK + (t & 3) * 8;                 // this thread's 8 k-values of a 64 x 32 sub-tile
-    const int fo = (lane & 15) * LDK + (lane >> 4) * 8;          // this lane's fragment offset inside a 16-row tile
-    for (int kt = 0; kt < KT; kt++) {
-        __syncthreads();
-#pragma unroll
-        for (int s2 = 0; s2 < KS; s2++)
-#pragma unroll
-            for (int q = 0; q < NP; q++) *reinterpret_cast<uint4*>(As + q * SA + so + s2 * K3) = ra[s2][q][0];
-        __syncthreads();
-        uint4 b[KS][NP][2];   // this iteration's weight fragments; the registers are refilled for the next one right away
-#pragma unroll
-        for (int s2 = 0; s2 < KS; s2++)
-#pragma unroll
-            for (int q = 0; q < NP; q++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) b[s2][q][j] = rb[s2][q][j];
-        if (kt + 1 < KT) { loadA(kt + 1); loadB(kt + 1); }
-#pragma unroll
-        for (int s2 = 0; s2 < KS; s2++) {
-            s16x8 a[NP][4];
-#pragma unroll
-            for (int q = 0; q < NP; q++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) a[q][i] = *reinterpret_cast<const s16x8*>(As + q * SA + (i * 16) * LDK + s2 * K3 + fo);
-            // part pairs outermost (smallest terms first): consecutive MFMAs write different accumulators (see t_gemm_sb)
-#define CV_PASS(qa, qb)                                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < 4; i++) _Pragma("unroll") for (int j = 0; j < 2; j++)                           \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[qa][i]), __builtin_bit_cast(bf16x8, b[s2][qb][j]), acc[i][j], 0, 0, 0)
-            if constexpr (NP == 3) { CV_PASS(2, 0); CV_PASS(0, 2); CV_PASS(1, 1); }
-            CV_PASS(1, 0);
-            CV_PASS(0, 1);
-            CV_PASS(0, 0);
-#undef CV_PASS
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int row = m0 + i * 16 + 4 * (lane >> 4) + e;
-                const int col = (nt0 + j) * 16 + (lane & 15);
-                if (row < M) C[(size_t)row * NF + col] = acc[i][j][e];
-            }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2129,9 +1881,6 @@ __global__ void t_adam(float* __restrict__ w, const float* __restrict__ g, float
 // =====================================================================================================================
 // conv GEMM arithmetic: split bf16 (default; 6-pass forward, 3-pass backward) or the fp32 MFMA (AZR_TRAIN_GEMM=f32)
 bool g_gemm_bf16x3 = true;
-// which split-bf16 conv kernels: t_conv_rs (default) or the older t_conv_sb (AZR_TRAIN_GEMM=sb: kept as the second
-// implementation the tests compare against)
-bool g_conv_rs = true;
 // forward conv arithmetic: fp16 pairs, 3 passes (default) or three bf16 parts, 6 passes (AZR_TRAIN_FWD=bf16)
 bool g_fwd_f16 = true;
 constexpr float FWD_WSCALE = 1024.0f;   // the packed forward kernels are 2^10 * W: |w| < 64 stays inside fp16, a weight of 1e-4 keeps a normal low part
@@ -2212,7 +1961,6 @@ int ctx_ensure(azr_engine* h, int BS)
     if (c && c->BS == BS) return AZR_OK;
     // tuning switch, read when a training context is (re)built — never in the step path
     g_gemm_bf16x3 = !(getenv("AZR_TRAIN_GEMM") && strcmp(getenv("AZR_TRAIN_GEMM"), "f32") == 0);
-    g_conv_rs = !(getenv("AZR_TRAIN_GEMM") && strcmp(getenv("AZR_TRAIN_GEMM"), "sb") == 0);
     g_fuse_bwd = !(getenv("AZR_TRAIN_FUSE") && atoi(getenv("AZR_TRAIN_FUSE")) == 0);
     g_fwd_f16 = !(getenv("AZR_TRAIN_FWD") && strcmp(getenv("AZR_TRAIN_FWD"), "bf16") == 0);
     g_fuse_apply = !(getenv("AZR_TRAIN_FUSE_APPLY") && atoi(getenv("AZR_TRAIN_FUSE_APPLY")) == 0);
@@ -2314,15 +2062,6 @@ void gemm(hipStream_t st, const float* A, int lda, const float* B, int ldb, floa
                        C, ldc, M, N, K, kchunk, strideCz);
 }
 
-template <bool A_MCONTIG, bool B_KCONTIG, int BM, int AMODE, int BMODE, int NP>
-void gemm_sb(hipStream_t st, Parts A, int lda, Parts B, int ldb, float* C, int ldc, int M, int N, int K, int nz = 1, int kchunk = 0,
-             size_t strideCz = 0)
-{
-    if (nz == 1) kchunk = K;
-    hipLaunchKernelGGL((t_gemm_sb<A_MCONTIG, B_KCONTIG, BM, AMODE, BMODE, NP>), dim3((N + GT - 1) / GT, (M + BM - 1) / BM, nz), dim3(256), 0,
-                       st, A, lda, B, ldb, C, ldc, M, N, K, kchunk, strideCz);
-}
-
 inline dim3 grid1(size_t n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 // RCCL, bound at run time: dlopen("librccl.so.1") returns the copy a host process has already loaded (PyTorch-ROCm ships one under
@@ -2405,7 +2144,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     auto Al = [&](int l) { return c->A + act * l; };
     const unsigned g4 = (unsigned)((act / 4 + 255) / 256);
     const bool sb = g_gemm_bf16x3 && M % K3 == 0;  // split-bf16 conv GEMMs (the stem, K = 144, stays on the fp32 MFMA)
-    const bool f16 = sb && g_conv_rs && g_fwd_f16; // forward conv: fp16 pairs, 3 passes
+    const bool f16 = sb && g_fwd_f16;              // forward conv: fp16 pairs, 3 passes
     // small batches (a rank's share of a data-parallel minibatch): one board x 64 channels per block (t_conv_q) instead of 2 boards x 256
     const bool convq = f16 && g_fuse_bwd && g_fuse_apply && g_conv_q && BS <= 128;
     auto Wpf = [&](int l) { const size_t o = (size_t)(l - 1) * KC * NF; return Parts{{c->wpf[0] + o, c->wpf[1] + o, c->wpf[2] + o}}; };
@@ -2461,8 +2200,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
                                    BwdFuse{nullptr, nullptr, nullptr, nullptr, nullptr, c->part}, 1.0f / FWD_WSCALE, ProFuse{});
             } else if (f16) hipLaunchKernelGGL((t_conv_rs<1, 2, 0, true>), dim3((BS + 1) / 2), dim3(256), 0, st, Parts{{c->af[0], c->af[1], nullptr}}, Wpf(l), Yl(l), BS,
                                         BwdFuse{}, 1.0f / FWD_WSCALE, ProFuse{});
-            else if (g_conv_rs) hipLaunchKernelGGL((t_conv_rs<1, 3>), dim3((BS + 1) / 2), dim3(256), 0, st, Ap(l - 1), Wpf(l), Yl(l), BS, BwdFuse{}, 1.0f, ProFuse{});
-            else hipLaunchKernelGGL((t_conv_sb<1, 3, 1>), dim3(2, (M + 63) / 64), dim3(256), 0, st, Ap(l - 1), Wpf(l), Yl(l), M);
+            else hipLaunchKernelGGL((t_conv_rs<1, 3>), dim3((BS + 1) / 2), dim3(256), 0, st, Ap(l - 1), Wpf(l), Yl(l), BS, BwdFuse{}, 1.0f, ProFuse{});
         } else gemm<false, false, 64, 1, 0>(st, Al(l - 1), KC, Wl(l), NF, Yl(l), NF, M, NF, KC);
         const int Rf = fwd_parts ? fwd_parts : R;
         if (!fwd_parts) hipLaunchKernelGGL((t_bn_stats<false>), dim3(R), dim3(1024), 0, st, Yl(l), M, c->part);
@@ -2500,7 +2238,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     // (t_conv_rs<2, 2, 1>, the backward-data conv of layer l, leaves stage 1 of layer l - 1's batch-norm backward behind: its
     //  block partials are then already in c->part, `fused_parts` blocks of them)
     int fused_parts = 0;
-    const bool fuse = sb && g_conv_rs && g_fuse_bwd;
+    const bool fuse = sb && g_fuse_bwd;
     for (int l = c->L - 1; l >= 1; l--) {
         // gradient w.r.t. this layer's post-activation output: G for the second conv of a block, DT for the first
         const bool second = (l % 2 == 0);
@@ -2548,10 +2286,9 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
                            invM, sb ? (float*)nullptr : c->dY, second ? c->DS : (float*)nullptr, M, sb ? c->dyp[0] : nil16, c->dyp[1]);
         // dW = col(input)^T x dY  (implicit im2col, split-K over the M rows)
         if (sb) {
-            if (g_conv_rs) hipLaunchKernelGGL(t_wgrad_rs, dim3(64 * c->wg_slices), dim3(64), Wg::LDS_BYTES, st, apP, dyP, c->wpart, M, c->wg_slices, c->wg_rows);
-            else gemm_sb<true, false, 128, 1, 0, 2>(st, apP, KC, dyP, NF, c->wpart, NF, KC, NF, M, c->nz, c->kchunk, wn);
+            hipLaunchKernelGGL(t_wgrad_rs, dim3(64 * c->wg_slices), dim3(64), Wg::LDS_BYTES, st, apP, dyP, c->wpart, M, c->wg_slices, c->wg_rows);
         } else gemm<true, false, 128, 1, 0>(st, Al(l - 1), KC, c->dY, NF, c->wpart, NF, KC, NF, M, c->nz, c->kchunk, wn);
-        hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, (sb && g_conv_rs) ? c->wg_slices : c->nz, wn, Gl(l));
+        hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, sb ? c->wg_slices : c->nz, wn, Gl(l));
         // d(input) = transposed conv of dY with W: the same implicit GEMM with negated taps and W read as [tap][co] x [ci]
         fused_parts = 0;
         if (fuse && l >= 2) {   // + the shortcut gradient (first conv of a block), + stage 1 of layer l - 1's BN backward
@@ -2561,8 +2298,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
                                        c->istd + (l - 1) * NF, c->part}, 1.0f, ProFuse{});
             continue;
         }
-        if (sb && g_conv_rs) hipLaunchKernelGGL((t_conv_rs<2, 2>), dim3((BS + 1) / 2), dim3(256), 0, st, dyP, Wpb(l), dIn, BS, BwdFuse{}, 1.0f, ProFuse{});
-        else if (sb) hipLaunchKernelGGL((t_conv_sb<2, 2, 1>), dim3(2, (M + 63) / 64), dim3(256), 0, st, dyP, Wpb(l), dIn, M);
+        if (sb) hipLaunchKernelGGL((t_conv_rs<2, 2>), dim3((BS + 1) / 2), dim3(256), 0, st, dyP, Wpb(l), dIn, BS, BwdFuse{}, 1.0f, ProFuse{});
         else gemm<false, true, 64, 2, 3>(st, c->dY, KC, Wl(l), NF, dIn, NF, M, NF, KC);
         if (!second) hipLaunchKernelGGL(t_add, dim3(g4), dim3(256), 0, st, dIn, c->DS, act / 4);  // + shortcut gradient
     }

@@ -68,7 +68,8 @@ def test_checkpoint_roundtrip(tmp_path):
 def test_bf16_mfma_tower_matches_fp32_oracle(orc, n, blocks):
     """bf16 MFMA path (bf16 weights and inter-layer activations, fp32 accumulate/epilogue) vs the fp32 oracle.
     Stated tolerance: max |dpi| <= 2e-2, max |dv| <= 2e-2; typical error is ~1e-3.
-    n selects the 1-, 2- and 3-boards-per-workgroup variants (M = 48 / 96 / 128) and the mixed 3/2 launch."""
+    n selects the tile: up to 256 boards one per workgroup (k_tower_bf16<1>), above that the single-image tiles of 2, 3 or 4
+    boards (k_tower_sb<NB>, the planner's choice)."""
     P = pkg()
     base = sample_inputs(64)
     x = np.concatenate([base] * ((n + 63) // 64))[:n].copy()
@@ -83,7 +84,6 @@ def test_bf16_mfma_tower_matches_fp32_oracle(orc, n, blocks):
     assert dpi <= 2e-2 and dv <= 2e-2, (dpi, dv)
     assert np.allclose(pi.sum(1), 1.0, atol=1e-5)
     # identical inputs in different slots / workgroup shapes give identical bits (batch invariance)
-    # (n = 600 / 1100 run the mixed launch: 3-board workgroups first, 2-board workgroups after)
     for k in range(64, n - 63, 64):
         assert (pi[:64].view(np.uint32) == pi[k:k + 64].view(np.uint32)).all(), k
         assert (v[:64] == v[k:k + 64]).all(), k
@@ -95,9 +95,9 @@ def test_bf16_mfma_tower_matches_fp32_oracle(orc, n, blocks):
 @pytest.mark.parametrize("n", [512, 768, 1024, 2048, 4096])
 def test_bf16_tower_at_depth_matches_fp32_oracle(orc, n):
     """the tiles the bench really launches, at the bench's depth (B = 20, 41 conv layers): n = 512 -> 2 boards per
-    workgroup, 768 -> 3, 1024 -> the 512 x 100 x T=2 north-star batch, 2048 / 4096 -> the mixed launches of
-    BASELINE configs[2].  128 DISTINCT boards are compared with the fp32 oracle: 64 in the first workgroups and 64
-    others in the last ones (in a mixed launch those are the smaller tile); every other 64-slot group repeats the first
+    workgroup, 768 -> 3, 1024 -> the 512 x 100 x T=2 north-star batch, 2048 / 4096 -> the 4-board tile in 2 / 4 rounds
+    (BASELINE configs[2]).  128 DISTINCT boards are compared with the fp32 oracle: 64 in the first workgroups and 64
+    others in the last ones; every other 64-slot group repeats the first
     and must be bit-identical to it.  Stated tolerance 2e-2 on pi and v (spec: build_graph.py:63-90)."""
     P = pkg()
     blocks = 20
@@ -120,7 +120,7 @@ def test_bf16_tower_at_depth_matches_fp32_oracle(orc, n):
     for k in range(64, n - 127, 64):
         assert (pi[:64].view(np.uint32) == pi[k:k + 64].view(np.uint32)).all(), k
         assert (v[:64] == v[k:k + 64]).all(), k
-    # the tail boards again in the FIRST workgroups (another tile shape in a mixed launch): same bits
+    # the tail boards again in the FIRST workgroups: same bits
     p2, v2 = eng.predict(np.concatenate([tail, x[64:]]))
     assert (p2[:64].view(np.uint32) == pi[n - 64:].view(np.uint32)).all() and (v2[:64] == v[n - 64:]).all()
     eng.close()
@@ -196,8 +196,9 @@ def test_f32x_refuses_weights_outside_the_fp16_range():
 
 @pytest.mark.parametrize("blocks", [20, 1, 2])
 def test_tile_shapes_agree_bit_for_bit(monkeypatch, blocks):
-    """the 4- and 2-boards-per-workgroup single-buffer kernels (azr_tower_sb.hip) and the 1..3-board kernels compute the same
-    bits: same k order, same fp32 epilogue, same rounding points (AZR_TOWER_SB is read once, at engine creation)"""
+    """the single-image tiles of 2, 3 and 4 boards per workgroup (k_tower_sb<NB>, azr_tower_sb.hip), the planner's choice among
+    them, and the independently written two-image kernel with one board per workgroup (k_tower_bf16<1>, AZR_TOWER_SB=0) compute
+    the same bits: same k order, same fp32 epilogue, same rounding points (the switch is read once, at engine creation)"""
     P = pkg()
     n = 1024
     g = np.unique(np.load(os.path.join(T.GOLDEN, "encode.npz"))["in88"], axis=0)
@@ -215,7 +216,7 @@ def test_tile_shapes_agree_bit_for_bit(monkeypatch, blocks):
             pm, vm = eng.predict(x[:m])
             assert (pm.view(np.uint32) == out[mode][0][:m].view(np.uint32)).all() and (vm == out[mode][1][:m]).all(), (mode, m)
         eng.close()
-    for mode in ("1", "2", "3", "4"):   # the planned mix, then 4- / 2- / 3-board single-image tiles, against the two-image kernels
+    for mode in ("1", "2", "3", "4"):   # the plan, then the 4- / 2- / 3-board single-image tiles, against the two-image kernel
         assert (out["0"][0].view(np.uint32) == out[mode][0].view(np.uint32)).all(), mode
         assert (out["0"][1].view(np.uint32) == out[mode][1].view(np.uint32)).all(), mode
 

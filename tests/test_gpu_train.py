@@ -100,17 +100,17 @@ def tf_adam(w, g, m, v, t, k):
     return np.where(tr, w2, w), np.where(tr, m2, m), np.where(tr, v2, v)
 
 
-@pytest.mark.parametrize("blocks,bs,gemm", [(1, 16, "split"), (2, 64, "split"), (2, 64, "r2"), (2, 64, "sb"), (2, 64, "f32"), (1, 10, "split")])
+@pytest.mark.parametrize("blocks,bs,gemm", [(1, 16, "split"), (2, 64, "split"), (2, 64, "r2"), (2, 64, "f32"), (1, 10, "split")])
 def test_step_matches_torch_graph(blocks, bs, gemm, monkeypatch):
     """gemm = "split": the default step — t_conv_rs (2 boards per block in border-class row order) with the forward conv on fp16
     pairs (3 passes), the backward GEMMs on two bf16 parts, the normalise / statistics kernels fused into the convs' staging
     paths and epilogues; "r2": the same kernels as round 2 ran them (6-pass bf16 forward, separate normalise kernels:
-    AZR_TRAIN_FWD=bf16, AZR_TRAIN_FUSE=0); "sb": the older 64-row tiles (AZR_TRAIN_GEMM=sb); "f32": the fp32-MFMA GEMMs
+    AZR_TRAIN_FWD=bf16, AZR_TRAIN_FUSE=0); "f32": the fp32-MFMA GEMMs
     (AZR_TRAIN_GEMM=f32); batch 10 (42 * 10 rows, not a multiple of the 32-deep k-tile) takes the fp32 kernels by itself.  Batches of up to 128 records run the small-batch
     conv kernel (t_conv_q) and 8-board weight-gradient slices."""
     for k in ("AZR_TRAIN_GEMM", "AZR_TRAIN_FWD", "AZR_TRAIN_FUSE", "AZR_TRAIN_FUSE_APPLY"):
         monkeypatch.delenv(k, raising=False)
-    if gemm in ("f32", "sb"):
+    if gemm == "f32":
         monkeypatch.setenv("AZR_TRAIN_GEMM", gemm)
     if gemm == "r2":
         monkeypatch.setenv("AZR_TRAIN_FWD", "bf16")
@@ -215,21 +215,25 @@ def test_step_on_unfiltered_records(blocks, bs):
 
 def test_conv_kernel_families_at_the_reference_batch(monkeypatch):
     """BATCH_SIZE 512 (the reference's; 256 two-board blocks of t_conv_rs, 16 row slices of 42 k-steps of t_wgrad_rs — the
-    shapes the learn loop runs): one step with the default conv kernels, one with the round-1 tiles (AZR_TRAIN_GEMM=sb) and
-    one with the fp32-MFMA GEMMs, against the float64 PyTorch graph.  With 27 M ReLU inputs per step some lie within fp32
-    rounding of zero (2.9e-8 here) and every implementation flips its own few masks, so single gradient entries differ by
-    up to 6e-3 of the tensor's largest between ANY two of them; the test bounds the relative L2 error per tensor instead
-    (measured: 3e-4 .. 1e-3 for the conv kernels of all three families alike, 1e-6 for the head tensors)"""
+    shapes the learn loop runs): one step with the default kernels (fp16-pair forward, fused normalise / statistics), one as
+    round 2 ran them (6-pass bf16 forward, separate kernels) and one with the fp32-MFMA GEMMs, against the float64 PyTorch
+    graph.  With 27 M ReLU inputs per step some lie within fp32 rounding of zero (2.9e-8 here) and every implementation flips
+    its own few masks, so single gradient entries differ by up to 6e-3 of the tensor's largest between ANY two of them; the
+    test bounds the relative L2 error per tensor instead (measured: 3e-4 .. 1e-3 for the conv kernels of all families alike,
+    1e-6 for the head tensors)"""
     P = pkg()
     blocks, bs = 2, 512
     flat = T.make_net_flat(blocks, seed=21, perturb_bn=True)
     rec = records(bs, seed=77)
     rlp, rlv, rg, _ = torch_step(blocks, flat, rec)
-    for mode in ("rs", "sb", "f32"):
-        if mode == "rs":
-            monkeypatch.delenv("AZR_TRAIN_GEMM", raising=False)
-        else:
-            monkeypatch.setenv("AZR_TRAIN_GEMM", mode)
+    for mode in ("default", "r2", "f32"):
+        for k in ("AZR_TRAIN_GEMM", "AZR_TRAIN_FWD", "AZR_TRAIN_FUSE"):
+            monkeypatch.delenv(k, raising=False)
+        if mode == "r2":
+            monkeypatch.setenv("AZR_TRAIN_FWD", "bf16")
+            monkeypatch.setenv("AZR_TRAIN_FUSE", "0")
+        if mode == "f32":
+            monkeypatch.setenv("AZR_TRAIN_GEMM", "f32")
         eng = P.Engine(8, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64)
         eng.set_weights(flat)
         lp, lv = eng.train_batch(rec)
