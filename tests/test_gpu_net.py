@@ -212,7 +212,7 @@ def test_tile_shapes_agree_bit_for_bit(monkeypatch, blocks):
         out[mode] = eng.predict(x)
         # ragged batches (last workgroup partly filled; in plan mode 700 / 400 boards take the 3- / 2-board tile) and a tiny
         # one take the same values
-        for m in (1023, 700, 400, 5):
+        for m in (1023, 700, 400, 256, 99, 5, 1):
             pm, vm = eng.predict(x[:m])
             assert (pm.view(np.uint32) == out[mode][0][:m].view(np.uint32)).all() and (vm == out[mode][1][:m]).all(), (mode, m)
         eng.close()
