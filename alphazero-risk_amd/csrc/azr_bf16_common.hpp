@@ -63,6 +63,9 @@ struct Bf16Net {
     uint16_t* tower_wp = nullptr;
     unsigned long long* diag = nullptr;  // set only by azr_debug_tower_clock
     int sb_mode = 1;   // use of the single-image tiles: 0 never, 1 plan, 2 / 3 / 4 force 4 / 2 / 3 boards (AZR_TOWER_SB, read once at creation)
+    int sc_mode = 1;   // launches of <= 256 boards on the split-channel tower (azr_tower_sc.hip); 0 = one board per workgroup (AZR_TOWER_SC, read once at creation)
+    uint16_t* sc_ex = nullptr;        // split-channel tower: the exchange images [2 parities][128 pairs][96 rows][256] bf16
+    unsigned* sc_counters = nullptr;  // ... the pairs' arrival counters [128] and the error word
 };
 inline Bf16Net* bf16net(azr_engine* h) { return reinterpret_cast<Bf16Net*>(h->net.bf16ctx); }
 const float* net_head_params(azr_engine* h);
@@ -70,4 +73,9 @@ const float* net_fold(azr_engine* h);
 // azr_tower_sb.hip
 int tower_sb_init(azr_engine* h);
 int tower_sb_launch(azr_engine* h, int nb, int wgs, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st);
+// azr_tower_sc.hip
+int tower_sc_init(azr_engine* h);
+void tower_sc_free(azr_engine* h);
+int tower_sc_launch(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st);
+int tower_sc_check(azr_engine* h);
 }  // namespace azr

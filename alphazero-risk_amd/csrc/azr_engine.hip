@@ -1213,6 +1213,7 @@ extern "C" int azr_mcts_simulate(azr_engine* h)
     std::vector<uint32_t> e(h->d.G);
     HIPCHK(h, hipMemcpy2DAsync(e.data(), 4, &h->d.ctl[0].error, sizeof(Ctl), 4, h->d.G, hipMemcpyDeviceToHost, h->stream));
     SYNC(h);
+    { int rcn = net_check(h); if (rcn) return rcn; }
     for (int g = 0; g < h->d.G; g++)
         if (e[g]) { h->err = "search error in game " + std::to_string(g) + " code " + std::to_string(e[g]); return (int)e[g]; }
     return AZR_OK;
@@ -1345,6 +1346,7 @@ extern "C" int azr_selfplay_run(azr_engine* h, int passes)
         if (prof) { HIPCHK(h, hipEventRecord(h->ev[3 * k + 2], h->stream)); k++; }
     }
     SYNC(h);
+    { int rcn = net_check(h); if (rcn) return rcn; }
     double tn = 0, tt = 0, tw = 0;
     const bool tower_timed = h->cfg.net_dtype == AZR_NET_BF16 || h->cfg.net_dtype == AZR_NET_F32X;   // one kernel = one net forward, bracketed by events
     for (int i = 0; i < k; i++) {
@@ -1536,6 +1538,8 @@ extern "C" int azr_arena_run(azr_engine* h, int passes, int* finished_out)
     std::vector<uint32_t> st(h->d.G);
     HIPCHK(h, hipMemcpy2DAsync(st.data(), 4, &h->d.ctl[0].arena_state, sizeof(Ctl), 4, h->d.G, hipMemcpyDeviceToHost, h->stream));
     SYNC(h);
+    { int rcn = net_check(h); if (rcn) return rcn; }
+    if (h->opponent) { int rcn = net_check(h->opponent); if (rcn) { h->err = h->opponent->err; return rcn; } }
     int idle = 0;
     for (uint32_t v : st) idle += v == 2;
     if (finished_out) *finished_out = idle == h->d.G;

@@ -132,6 +132,7 @@ int net_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, floa
 int net_forward_ex(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st);
 size_t net_param_count(int blocks);
 void net_init_random(float* flat, int blocks, uint64_t seed);
+int net_check(azr_engine* h);   // deferred device-side error words (read at the caller's synchronisation points)
 // NET_F32X (azr_tower_fx.hip)
 int net_fx_alloc(azr_engine* h);
 void net_fx_free(azr_engine* h);

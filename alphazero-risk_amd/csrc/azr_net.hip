@@ -403,6 +403,13 @@ int azr::net_forward_ex(azr_engine* h, const uint8_t* d_in88, int in_stride, int
     return net_bf16_forward(h, d_in88, in_stride, n, d_pi, d_v, d_map, st);
 }
 
+namespace azr { int tower_sc_check(azr_engine* h); }   // azr_tower_sc.hip
+int azr::net_check(azr_engine* h)
+{
+    if (h->cfg.net_dtype == AZR_NET_BF16 && h->net.bf16ctx) return tower_sc_check(h);
+    return AZR_OK;
+}
+
 // ---- C-ABI: AlphaZeroNNId ----------------------------------------------------------------------------
 #define ENTER(h)                                 \
     if (!(h)) return AZR_E_BAD_HANDLE;           \
@@ -507,5 +514,6 @@ extern "C" int azr_nn_predict(azr_engine* h, const void* in88, int n, float* pi,
         if (pi) for (int i = 0; i < m; i++) memcpy(pi + (size_t)(base + i) * 43, s_pi + (size_t)i * PI_STRIDE, 43 * 4);
         if (v) memcpy(v + base, s_v, (size_t)m * 4);
     }
+    if (rc == AZR_OK) rc = net_check(h);
     return rc;
 }

@@ -571,6 +571,10 @@ int net_bf16_alloc(azr_engine* h)
     // workgroup) for every launch — the independently written implementation the single-image tiles are compared with bit for bit;
     // 1 (default): plan; 2 / 3 / 4: force the 4- / 2- / 3-board single-image tile
     x->sb_mode = getenv("AZR_TOWER_SB") ? atoi(getenv("AZR_TOWER_SB")) : 1;
+    // AZR_TOWER_SC=0: launches of <= 256 boards on k_tower_bf16<1> instead of the split-channel tower (A/B measurements)
+    x->sc_mode = getenv("AZR_TOWER_SC") ? atoi(getenv("AZR_TOWER_SC")) : 1;
+    int rc = tower_sc_init(h);
+    if (rc) return rc;
     return tower_sb_init(h);
 }
 
@@ -578,6 +582,7 @@ void net_bf16_free(azr_engine* h)
 {
     if (!h->net.bf16ctx) return;
     Bf16Net* x = bn(h);
+    tower_sc_free(h);
     if (x->stem_wp) hipFree(x->stem_wp);
     if (x->tower_wp) hipFree(x->tower_wp);
     delete x;
@@ -658,7 +663,12 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
         if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
         return rc;
     }
-    // up to 256 boards (or AZR_TOWER_SB=0): one board per workgroup, two ping-pong images, 8 waves x 32 channels
+    if (x->sb_mode != 0 && x->sc_mode != 0 && n <= 128) {   // up to 128 boards: a board pair's channels split over 4 workgroups (azr_tower_sc.hip)
+        int rc = tower_sc_launch(h, d_in88, in_stride, n, d_pi, d_v, d_map, st);
+        if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
+        return rc;
+    }
+    // AZR_TOWER_SB=0 / AZR_TOWER_SC=0: one board per workgroup for the whole net, two ping-pong images, 8 waves x 32 channels
     hipLaunchKernelGGL((k_tower_bf16<1, 2>), dim3(n), dim3(512), Geo<1>::LDS_BYTES, st, d_in88, in_stride, n, x->stem_wp, x->tower_wp, fold, B,
                        net_head_params(h), d_pi, d_v, x->diag, n, d_map);
     if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
@@ -697,6 +707,11 @@ extern "C" int azr_debug_tower_plan(azr_engine* h, int n, int* boards_per_wg, in
     if (!h || !h->net.bf16ctx || n < 1) return AZR_E_STATE;
     const int snb = plan_sb(bn(h)->sb_mode, n);
     if (snb) { *boards_per_wg = snb; *wgs = (n + snb - 1) / snb; return AZR_OK; }
+    if (bn(h)->sb_mode != 0 && bn(h)->sc_mode != 0 && n <= 128) {   // split-channel tower: 4 workgroups of 64 channels per board pair
+        *wgs = ((n + 1) / 2) * 4;
+        *boards_per_wg = 2;
+        return AZR_OK;
+    }
     *wgs = n;   // one board per workgroup (k_tower_bf16<1>)
     *boards_per_wg = 1;
     return AZR_OK;
