@@ -327,11 +327,15 @@ __device__ __forceinline__ void consume_pending(const Dev& E, int g, const Tree&
         uint64_t valid = rfl64(E.leaf_valid[slot]);
         uint32_t kd = reinterpret_cast<const uint32_t*>(E.leaf_key + slot * GREC)[l & 15u];
         uint32_t h = rfl(E.leaf_hash[slot]);
+        TP(1);
         if (E.T > 1 && tree_lookup(t, kd, h) != NO_NODE) c.dup_dropped++;
         else {
+            TP(2);
             float prior = normalize_prior(pi, valid);
+            TP(3);
             if (tree_expand(t, c, kd, h, valid, prior) == NO_NODE) k.drop++;
         }
+        TP(4);
         k.evals++;
         const uint32_t plen = plen_get(c, th);
         if (plen > 0) {  // plen == 0: this was setRootState's root expansion (not a simulation)
@@ -339,6 +343,7 @@ __device__ __forceinline__ void consume_pending(const Dev& E, int g, const Tree&
             c.sims_done++;
             k.sims++;
         }
+        TP(5);
     }
     c.pending = 0;
 }
@@ -362,33 +367,47 @@ __device__ __forceinline__ int run_descents(const Dev& E, int g, const Tree& t0,
         s.err = 0;
         uint32_t plen = 0;
         bool leaf = false, fail = false;
+        TP(6);
         for (;;) {
             int gs = game_status(s, R);
+            TP(7);
             if (gs != ST_NOT_ENDED) {
                 float v = gs == ST_DRAW ? 0.0f : (gs == (int)s.cur ? 1.0f : -1.0f);
                 tree_backup(t, plen, v);
                 c.sims_done++;
                 k.sims++;
+                TP(5);
                 break;
             }
             uint64_t valid = valid_moves(s, R);
+            TP(8);
             if (valid == 0) { fail = true; s.err = E_INVALID_ARGUMENT; break; }
             uint32_t kd = ws_record_dword(s);
             uint32_t h = key_hash(kd);
+            TP(9);
             uint32_t idx = tree_lookup(t, kd, h);
+            TP(10);
             if (idx == NO_NODE) {  // leaf: hand the position to the NN service
                 encode88(s, E.leaf_in + slot * LEAF_STRIDE);
                 const uint32_t l = lane_id();
                 if (l < 16) reinterpret_cast<uint32_t*>(E.leaf_key + slot * GREC)[l] = kd;
                 if (l == 0) { E.leaf_valid[slot] = valid; E.leaf_hash[slot] = h; }
                 leaf = true;
+                TP(11);
                 break;
             }
             k.levels++;
             uint32_t mv = tree_select(t, idx, S, c.search_id, scratch);
+            TP(12);
             if (mv == NONE) { fail = true; s.err = E_LOGIC; break; }
             uint32_t before = s.cur;
+#ifdef AZR_TREE_PROF
+            const uint32_t ph0 = s.phase;
+#endif
             make_move(s, mv, R);
+#ifdef AZR_TREE_PROF
+            TP(ph0 == PH_FORTIFY ? 22 : ph0 == PH_ATTACK ? 23 : 13);
+#endif
             if (s.err) { fail = true; break; }
             if ((int)plen >= t.DMAX) { fail = true; s.err = AZR_E_CAPACITY; break; }
             if (lane_id() == 0) t.path[plen] = idx | (mv << 16) | ((s.cur != before ? 1u : 0u) << 24);
@@ -467,6 +486,7 @@ __global__ __launch_bounds__(64) void k_tree_step(Dev E)
 {
     __shared__ int8_t scratch[128];
     const int g = blockIdx.x;
+    TP_BEGIN();
     Ctl c;
     ctl_load(c, &E.ctl[g]);
     if (c.mode == 0 || (!SELFPLAY && c.search_done)) return;
@@ -477,8 +497,10 @@ __global__ __launch_bounds__(64) void k_tree_step(Dev E)
     ws_load(root, E.state + (size_t)g * GREC);
     StepCount k;
     bool root_dirty = false;
+    TP(0);
     consume_pending(E, g, t, c, k);
     for (;;) {
+        TP(6);
         if ((int)c.sims_done >= S.simulations) {
             if (!SELFPLAY) { c.search_done = 1; break; }
             // ---- one decision of the trainer's move loop (alphazero_trainer.cpp:91-112) ----
@@ -497,12 +519,14 @@ __global__ __launch_bounds__(64) void k_tree_step(Dev E)
                     c.nsamples++;
                 } else k.ringdrop++;
             }
+            TP(16);
             if (mv != NONE) make_move(root, mv, R); else root.err = E_LOGIC;
             c.last_move = mv;
             c.decisions++;
             k.dec++;
             c.rng = root.rng;
             int st = root.err ? ST_NOT_ENDED : game_status(root, R);
+            TP(17);
             if (root.err || st != ST_NOT_ENDED) {
                 if (root.err) { k.err++; c.error = root.err; }
                 else {
@@ -515,9 +539,11 @@ __global__ __launch_bounds__(64) void k_tree_step(Dev E)
                 selfplay_next_game(E, g, t, c, root);
             }
             root_dirty = true;
+            TP(18);
             if (c.mode == 0) break;  // quota exhausted: the slot idles
             tree_trim(t, c);
             c.sims_done = 0; c.sims_started = 0;
+            TP(14);
         }
         uint32_t err = 0;
         int r = search_round(E, g, t, c, root, scratch, k, err);
@@ -536,9 +562,13 @@ __global__ __launch_bounds__(64) void k_tree_step(Dev E)
             break;
         }
     }
+    TP(6);
     if (root_dirty) ws_store(root, E.state + (size_t)g * GREC);
+    TP(19);
     ctl_store(c, &E.ctl[g]);
+    TP(20);
     flush_counters(E, g, c, k, !SELFPLAY);
+    TP(21);
     // self-play tail (quota mode, slots going idle): the net of this pass runs on the waiting leaf slots only
     if (SELFPLAY && E.sp_compact && c.pending) {
         int base = 0;
@@ -547,6 +577,8 @@ __global__ __launch_bounds__(64) void k_tree_step(Dev E)
         const uint32_t l = lane_id();
         if (l < (uint32_t)E.T && ((c.pending >> l) & 1u)) E.leaf_list[base + (int)__builtin_popcount(c.pending & ((1u << l) - 1u))] = g * E.T + (int)l;
     }
+    TP(15);
+    TP_END();
 }
 
 // ================================================================================================
@@ -986,6 +1018,25 @@ extern "C" int azr_engine_destroy(azr_engine* h)
     train_free(h);
     net_free(h);
     for (hipEvent_t e : h->ev) hipEventDestroy(e);
+#ifdef AZR_TREE_PROF
+    {
+        unsigned long long t[25] = {0}, u[25] = {0}, hh[16] = {0};
+        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(azr::g_tprof), sizeof t);
+        (void)hipMemcpyFromSymbol(u, HIP_SYMBOL(azr::g_tslow), sizeof u);
+        (void)hipMemcpyFromSymbol(hh, HIP_SYMBOL(azr::g_thist), sizeof hh);
+        static const char* nm[24] = {"prologue", "consume: read leaf", "consume: dup lookup", "consume: normalize", "consume: expand", "backup",
+                                     "loop/copy root", "game_status", "valid_moves", "record+hash", "lookup", "leaf write", "select", "make_move", "decision: trim", "epilogue: leaf list",
+                                     "decision: policy+pick+stage", "decision: make_move+status", "decision: flush+next game", "epilogue: ws_store", "epilogue: ctl_store", "epilogue: counters", "make_move: fortify", "make_move: attack"};
+        if (t[24]) {
+            fprintf(stderr, "tree step profile: %llu waves, us per wave:", t[24]); double sum = 0;
+            for (int i = 0; i < 24; i++) { fprintf(stderr, " %s %.2f |", nm[i], t[i] * 0.01 / t[24]); sum += t[i] * 0.01 / t[24]; } fprintf(stderr, " total %.2f\n", sum);
+            if (u[24]) { fprintf(stderr, "  waves over 60 us: %llu, us per wave:", u[24]); for (int i = 0; i < 24; i++) fprintf(stderr, " %s %.2f |", nm[i], u[i] * 0.01 / u[24]); fprintf(stderr, "\n"); }
+            fprintf(stderr, "  waves by total time, 10-us bins:"); for (int i = 0; i < 16; i++) fprintf(stderr, " %llu", hh[i]); fprintf(stderr, "\n");
+            unsigned long long z[25] = {0};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(azr::g_tprof), z, sizeof z); (void)hipMemcpyToSymbol(HIP_SYMBOL(azr::g_tslow), z, sizeof z); (void)hipMemcpyToSymbol(HIP_SYMBOL(azr::g_thist), z, sizeof(unsigned long long) * 16);
+        }
+    }
+#endif
     if (h->arena_ev) hipEventDestroy(h->arena_ev);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;

@@ -103,6 +103,7 @@ struct CompW { uint64_t mask; uint32_t from, to, from_amount, to_nb; };
 __device__ __forceinline__ CompW flood_component(const WS& s, uint64_t owned, uint32_t start)
 {
     CompW c{1ULL << start, NONE, NONE, 0, 0};
+    const uint64_t pk = s.pk;   // adjacency lists in a VGPR (azr_wave.hpp)
     uint32_t stk = 0;  // lane i = stack entry i: land | next_neighbour_index << 8
     int sp = 0;
     stk = wrl(stk, 0, start);
@@ -121,9 +122,10 @@ __device__ __forceinline__ CompW flood_component(const WS& s, uint64_t owned, ui
         while (sp >= 0) {
             const uint32_t e = rdl(stk, (uint32_t)sp);
             const uint32_t l = e & 0xffu, i = e >> 8;
-            if (i >= c_deg[l]) { sp--; continue; }
+            const uint64_t row = rdl64(pk, l);
+            if (i >= (uint32_t)(row >> 56)) { sp--; continue; }
             stk = wrl(stk, (uint32_t)sp, l | ((i + 1) << 8));
-            const uint32_t n = c_nb[l][i];
+            const uint32_t n = (uint32_t)(row >> (8u * i)) & 0xffu;
             const uint64_t nbit = 1ULL << n;
             if ((owned & nbit) && !(c.mask & nbit)) {
                 c.mask |= nbit;

@@ -155,7 +155,11 @@ __device__ __forceinline__ void tree_clear(const Tree& t, Ctl& c)
 }
 
 // StateSimulationsStorage::trimNodes (alphazero_mcts.cpp:229-245): survivors = touched under the previous stamp.
-// Rebuilds the table and the free stack; node bodies do not move.
+// Rebuilds the table and the free stack; node bodies do not move.  The survivors of a 64-node chunk are re-inserted by their
+// lanes side by side (compare-and-swap on the empty slot, linear probing): which slot a key lands in depends on the order the
+// L2 retires the lanes' atomics, what a lookup returns does not (it compares tag and full key along the probe sequence, and
+// nothing is ever deleted from a table between two rebuilds).  One at a time the re-insertion was ~1 us per survivor — the
+// slowest wave of a tree step, the one the launch waits for, is a game that has just moved.
 __device__ __forceinline__ void tree_trim(const Tree& t, Ctl& c)
 {
     const uint32_t prev = c.search_id;
@@ -164,6 +168,7 @@ __device__ __forceinline__ void tree_trim(const Tree& t, Ctl& c)
     wave_mem_sync();
     uint32_t nfree = 0;
     const uint32_t hw = c.hiwater;
+    const uint32_t mask = (uint32_t)(t.H - 1);
     for (uint32_t base = 0; base < hw; base += 64) {
         uint32_t i = base + lane_id();
         uint32_t tc = i < hw ? t.touch[i] : 0u;
@@ -177,15 +182,19 @@ __device__ __forceinline__ void tree_trim(const Tree& t, Ctl& c)
             t.touch[i] = 0;
         }
         nfree += (uint32_t)popc64(dm);
-        uint64_t am = ballot64(alive);
-        while (am) {
-            uint32_t b = (uint32_t)ctz64(am);
-            am &= am - 1;
-            tree_insert(t, rdl(hv, b), base + b);
+        if (alive) {
+            const uint32_t entry = (hv & 0xffff0000u) | (i + 1u);
+            uint32_t slot = hv & mask;
+            for (int probes = 0; probes < t.H; probes++) {
+                if (atomicCAS(&t.table[slot], 0u, entry) == 0u) break;
+                slot = (slot + 1) & mask;
+            }
         }
     }
     c.nfree = nfree;
     wave_mem_sync();
+    // the atomics ran in L2: drop this CU's L1 lines of the table (cleared by plain stores above) before the wave's next lookups
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 // libstdc++ unordered_map<LandIndex,...> iteration order (alphazero_mcts.cpp:78): returns the key
@@ -298,9 +307,14 @@ __device__ __forceinline__ uint32_t tree_select(const Tree& t, uint32_t idx, con
 // NNOutputData::normalize (alphazero_nn_data.cpp:3-27): sequential fp32 sum over the legal entries, index order
 __device__ __forceinline__ float normalize_prior(float pi, uint64_t valid)
 {
+    // (an illegal entry adds +0.0f instead of being skipped: x + 0.0f == x bit for bit for the non-negative softmax outputs summed
+    //  here, and the 43 dependent adds run as straight-line code — with a branch per entry this was 1.5 us per leaf)
     float sum = 0.0f;
-    for (uint32_t i = 0; i < MOVES; i++)
-        if ((valid >> i) & 1ULL) sum = __fadd_rn(sum, rdlf(pi, i));
+#pragma unroll
+    for (uint32_t i = 0; i < MOVES; i++) {
+        const float x = rdlf(pi, i);
+        sum = __fadd_rn(sum, ((valid >> i) & 1ULL) ? x : 0.0f);
+    }
     const uint32_t l = lane_id();
     float p = (l < MOVES && ((valid >> l) & 1ULL)) ? pi : 0.0f;
     if (p > 0.0f) p = __fdiv_rn(p, sum);

@@ -39,7 +39,7 @@ struct Rules {  // src/settings.h:51-56
 // tests them (state/state.cpp:461-483: NA, SA, AF, EU, AS, AU; bonuses land/land_index.h:5-10).
 static __constant__ uint8_t c_deg[LANDS] = {3, 4, 4, 4, 6, 3, 4, 4, 3, 3, 3, 4, 2, 3, 4, 4, 6, 5, 6, 4, 6,
                                             4, 3, 6, 3, 2, 4, 5, 3, 5, 4, 2, 5, 5, 6, 6, 4, 3, 3, 3, 3, 2};
-static __constant__ uint8_t c_nb[LANDS][8] = {
+static __constant__ __attribute__((aligned(8))) uint8_t c_nb[LANDS][8] = {
     {1, 3, 29},         {0, 3, 4, 2},        {1, 4, 5, 13},       {0, 1, 4, 6},        {1, 3, 6, 7, 5, 2},
     {4, 7, 2},          {3, 4, 7, 8},        {8, 6, 4, 5},        {6, 7, 9},           {8, 10, 11},
     {9, 11, 12},        {9, 10, 12, 20},     {10, 11},            {2, 14, 15},         {13, 19, 15, 17},
@@ -55,6 +55,32 @@ static __constant__ int c_cont_bonus[6] = {5, 2, 3, 5, 7, 2};
 
 // ---- wave primitives -------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// Timing-experiment builds only (-DAZR_TREE_PROF, tools/tree_prof.sh; never the product library): lane 0 of the tree-step wave
+// adds the 100-MHz ticks since the previous mark to segment i; the kernel's last mark flushes the segments to g_tprof.
+#ifdef AZR_TREE_PROF
+__shared__ unsigned long long tp_acc[24];
+__shared__ unsigned long long tp_last;
+__device__ unsigned long long g_tprof[25];
+__device__ unsigned long long g_tslow[25];   // the same for waves that took more than 60 us
+__device__ unsigned long long g_thist[16];   // waves by total time, 10-us bins
+__device__ __forceinline__ void TP_BEGIN() { if (threadIdx.x == 0) { for (int i = 0; i < 24; i++) tp_acc[i] = 0; tp_last = wall_clock64(); } }
+__device__ __forceinline__ void TP(int i) { if (threadIdx.x == 0) { const unsigned long long n = wall_clock64(); tp_acc[i] += n - tp_last; tp_last = n; } }
+__device__ __forceinline__ void TP_END()
+{
+    if (threadIdx.x == 0) {
+        unsigned long long tot = 0;
+        for (int i = 0; i < 24; i++) { tot += tp_acc[i]; if (tp_acc[i]) atomicAdd(&g_tprof[i], tp_acc[i]); }
+        atomicAdd(&g_tprof[24], 1ull);
+        if (tot > 6000) { for (int i = 0; i < 24; i++) if (tp_acc[i]) atomicAdd(&g_tslow[i], tp_acc[i]); atomicAdd(&g_tslow[24], 1ull); }
+        atomicAdd(&g_thist[tot / 1000 > 15 ? 15 : tot / 1000], 1ull);
+    }
+}
+#else
+__device__ __forceinline__ void TP_BEGIN() {}
+__device__ __forceinline__ void TP(int) {}
+__device__ __forceinline__ void TP_END() {}
+#endif
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l)
 {
@@ -77,24 +103,33 @@ __device__ __forceinline__ uint64_t rdl64(uint64_t v, uint32_t l)
 __device__ __forceinline__ int popc64(uint64_t x) { return __builtin_popcountll(x); }
 __device__ __forceinline__ int ctz64(uint64_t x) { return __builtin_ctzll(x); }
 
+// PER LANE: the adjacency list of land `lane`, one byte per neighbour in declaration order, the degree in byte 7 (0 for lanes >= 42).
+// The depth-first walks below step through these lists one neighbour at a time: from a VGPR (v_readlane) a step is a few cycles,
+// from the constant tables it was two dependent scalar loads — a fortify move cost 30 - 40 us, the slowest waves of a mid-game tree step.
+__device__ __forceinline__ uint64_t lane_nbpack()
+{
+    const uint32_t l = lane_id();
+    if (l >= LANDS) return 0;
+    return *reinterpret_cast<const uint64_t*>(&c_nb[l][0]) | ((uint64_t)c_deg[l] << 56);
+}
+
 // ---- the wave-resident game ------------------------------------------------------------------------------
 struct WS {
     uint32_t la;   // PER LANE: land byte for lanes < 42; 0xC0 (owner 3 = nobody) for lanes >= 42
     uint64_t nbm;  // PER LANE: neighbour mask of land `lane` (0 for lanes >= 42)
+    uint64_t pk;   // PER LANE: neighbour LIST of land `lane` (lane_nbpack: one byte per neighbour in declaration order, degree in byte 7)
     // wave-uniform
     uint32_t cur, card_sets, reinf, phase, mob_from, mob_to, allow_draw, attacks, round, cards0, cards1;
     uint32_t rng;  // minstd_rand0 engine state of this game's stream
     uint32_t err;  // first rules error (E_*)
 };
 
-__device__ __forceinline__ uint64_t lane_nbmask()
+__device__ __forceinline__ uint64_t nbmask_of(uint64_t pk)
 {
-    uint32_t l = lane_id();
     uint64_t m = 0;
-    if (l < LANDS) {
-        int d = c_deg[l];
-        for (int i = 0; i < d; i++) m |= 1ULL << c_nb[l][i];
-    }
+    const uint32_t d = (uint32_t)(pk >> 56);
+#pragma unroll
+    for (uint32_t i = 0; i < 6; i++) m |= i < d ? 1ULL << ((pk >> (8u * i)) & 0xffu) : 0ULL;
     return m;
 }
 
@@ -136,7 +171,8 @@ __device__ __forceinline__ uint32_t cards_of(const WS& s, uint32_t p) { return p
 __device__ __forceinline__ void ws_blank(WS& s)  // `State()` (state/state.h:86-105 default member initialisers)
 {
     s.la = lane_id() < LANDS ? 0x80u : 0xC0u;
-    s.nbm = lane_nbmask();
+    s.pk = lane_nbpack();
+    s.nbm = nbmask_of(s.pk);
     s.cur = 0; s.card_sets = 0; s.reinf = 0; s.phase = PH_SETUP; s.mob_from = NONE; s.mob_to = NONE;
     s.allow_draw = 0; s.attacks = 0; s.round = 1; s.cards0 = 0; s.cards1 = 0;
     s.err = 0;
@@ -148,7 +184,8 @@ __device__ __forceinline__ void ws_load(WS& s, const uint8_t* rec)
     uint32_t l = lane_id();
     uint32_t b = rec[l];
     s.la = l < LANDS ? b : 0xC0u;
-    s.nbm = lane_nbmask();
+    s.pk = lane_nbpack();
+    s.nbm = nbmask_of(s.pk);
     s.cur = rdl(b, GR_CUR); s.card_sets = rdl(b, GR_CARD_SETS); s.reinf = rdl(b, GR_REINF);
     s.phase = rdl(b, GR_PHASE); s.mob_from = rdl(b, GR_MOB_FROM); s.mob_to = rdl(b, GR_MOB_TO);
     s.allow_draw = rdl(b, GR_ALLOW_DRAW); s.attacks = rdl(b, GR_ATTACKS);
@@ -448,9 +485,31 @@ __device__ __forceinline__ void fortify_pick(const WS& s, uint32_t target, uint3
         if (grow == comp) break;
         comp = grow;
     }
+    // The walk below only decides TIES: a source is the candidate of its class (all neighbours owned / some not) with the largest
+    // movable army, the first such in pre-order.  A unique maximum needs no order: found lane-parallel, one ballot per value bit.
+    {
+        const uint32_t l = lane_id();
+        const uint32_t value = ((s.la & 63u) - 1u) & 0xffu;
+        const bool cand = ((comp >> l) & 1ULL) && l != target && value > 0;
+        const bool inner = (s.nbm & owned) == s.nbm;
+        uint64_t ci = ballot64(cand && inner), cb = ballot64(cand && !inner);
+#pragma unroll
+        for (int b = 7; b >= 0; b--) {
+            const uint64_t hi = ballot64((value >> b) & 1u);
+            ci = (ci & hi) ? (ci & hi) : ci;
+            cb = (cb & hi) ? (cb & hi) : cb;
+        }
+        const uint64_t pick = ci ? ci : cb;
+        if ((pick & (pick - 1)) == 0) {   // none, or exactly one
+            from_out = pick ? (uint32_t)ctz64(pick) : NONE;
+            amount_out = pick ? ((rdl(s.la, from_out) & 63u) - 1u) & 0xffu : 0u;
+            return;
+        }
+    }
     const uint32_t start = (uint32_t)ctz64(comp);
     uint32_t best_nn = 0, best = 0, from_nn = NONE, from = NONE;
     uint64_t visited = 1ULL << start;
+    const uint64_t pk = s.pk;
     uint32_t stk = 0;      // lane i = stack entry i: land | next_neighbour_index << 8
     int sp = 0;
     stk = wrl(stk, 0, start);
@@ -472,9 +531,10 @@ __device__ __forceinline__ void fortify_pick(const WS& s, uint32_t target, uint3
         while (sp >= 0) {
             uint32_t e = rdl(stk, (uint32_t)sp);
             uint32_t l = e & 0xffu, i = e >> 8;
-            if (i >= c_deg[l]) { sp--; continue; }
+            const uint64_t row = rdl64(pk, l);
+            if (i >= (uint32_t)(row >> 56)) { sp--; continue; }
             stk = wrl(stk, (uint32_t)sp, l | ((i + 1) << 8));
-            uint32_t n = c_nb[l][i];
+            uint32_t n = (uint32_t)(row >> (8u * i)) & 0xffu;
             uint64_t nbit = 1ULL << n;
             if ((owned & nbit) && !(visited & nbit)) {
                 visited |= nbit;
@@ -533,15 +593,27 @@ __device__ __forceinline__ void make_move(WS& s, uint32_t li, const Rules& R)
         set_land(s, li, t_army + amount, p);
         if (s.reinf == 0) goto_attack(s);
     } else if (s.phase == PH_ATTACK) {  // alphazero_moves.cpp:122-144
-        const uint64_t oa = m_owned_army(s, p);
-        uint32_t best_army = 0, best_from = NONE;
-        const int d = c_deg[li];
-        for (int i = 0; i < d; i++) {
-            uint32_t nl = c_nb[li][i];
-            if (oa & (1ULL << nl)) {
-                uint32_t aa = ((rdl(s.la, nl) & 63u) - 1u) & 0xffu;
-                if (aa > best_army) { best_army = aa; best_from = nl; }
+        // the owned neighbour with the largest army to spare, the first such in the target's neighbour list: lane-parallel maximum
+        // (one ballot per value bit); the list (s.pk, a register) is walked only when the maximum is tied
+        uint32_t best_from = NONE;
+        {
+            const uint32_t l = lane_id();
+            const uint64_t nbt = rdl64(s.nbm, li);
+            const uint32_t value = ((s.la & 63u) - 1u) & 0xffu;
+            uint64_t cs = ballot64(((nbt >> l) & 1ULL) && w_owner(s) == p && w_army(s) > 1);   // (army > 1 => value > 0)
+#pragma unroll
+            for (int b = 7; b >= 0; b--) {
+                const uint64_t hi = ballot64((value >> b) & 1u);
+                cs = (cs & hi) ? (cs & hi) : cs;
             }
+            if (cs & (cs - 1)) {
+                const uint64_t row = rdl64(s.pk, li);
+                const uint32_t d = (uint32_t)(row >> 56);
+                for (uint32_t i = 0; i < d; i++) {
+                    const uint32_t nl = (uint32_t)(row >> (8u * i)) & 0xffu;
+                    if ((cs >> nl) & 1ULL) { best_from = nl; break; }
+                }
+            } else if (cs) best_from = (uint32_t)ctz64(cs);
         }
         attack_move(s, best_from, li);
     } else if (s.phase == PH_ATTACK_MOBILIZATION) {  // alphazero_moves.cpp:145-171 + attackReinforcementMove (:920-947)
