@@ -1916,9 +1916,13 @@ struct TrainCtx {
     double* red = nullptr;     // [2 * NG][256] reduced BN partials
     double* hsum = nullptr;    // [6] head BN sums
     float* lr = nullptr;   // device: this step's bias-corrected learning rate
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t gexec = nullptr;
-    const void *graph_rec = nullptr, *graph_perm = nullptr, *graph_flat = nullptr;  // buffers the captured graph points at
+    // the weight-gradient branch of the backward pass (t_wgrad_rs + t_sum_slices of every layer) hangs off the gradient chain: nothing
+    // but Adam waits for it.  At small batches (<= 128 records: a rank's share of a data-parallel minibatch) it runs on a second,
+    // low-priority stream beside the chain's kernels, which leave most of the chip idle there: 4.22 -> 3.87 ms per step at 64 records.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_conv[2] = {nullptr, nullptr};   // main -> side: the backward-data conv of a layer has left its dY parts (by layer parity)
+    hipEvent_t ev_wg[2] = {nullptr, nullptr};     // side -> main: that layer's weight gradient has read them
+    uint16_t* dyp2[2] = {nullptr, nullptr};       // the dY parts of odd layers (a second set: the chain runs ahead of the branch)
     uint8_t* rec = nullptr;
     size_t rec_cap = 0;
     int* perm = nullptr;
@@ -1941,8 +1945,8 @@ int dalloc(azr_engine* h, TrainCtx* c, T** p, size_t n)
 void ctx_free(TrainCtx* c)
 {
     if (!c) return;
-    if (c->gexec) hipGraphExecDestroy(c->gexec);
-    if (c->graph) hipGraphDestroy(c->graph);
+    for (int q = 0; q < 2; q++) { if (c->ev_conv[q]) hipEventDestroy(c->ev_conv[q]); if (c->ev_wg[q]) hipEventDestroy(c->ev_wg[q]); }
+    if (c->side) hipStreamDestroy(c->side);
     for (void* p : c->allocs) hipFree(p);
     if (c->rec) hipFree(c->rec);
     if (c->perm) hipFree(c->perm);
@@ -2009,7 +2013,16 @@ int ctx_ensure(azr_engine* h, int BS)
     // pass wants exactly them: no second split), the third one only until the next forward conv has read it
     for (int q = 0; q < 3; q++) { TRY(dalloc(h, c, &c->ap[q], q < 2 ? act * c->L : act)); TRY(dalloc(h, c, &c->wpf[q], (size_t)2 * B * KC * NF)); }
     for (int q = 0; q < 2; q++) TRY(dalloc(h, c, &c->wpb[q], (size_t)2 * B * KC * NF));
-    for (int q = 0; q < 2; q++) TRY(dalloc(h, c, &c->dyp[q], act));
+    for (int q = 0; q < 2; q++) { TRY(dalloc(h, c, &c->dyp[q], act)); TRY(dalloc(h, c, &c->dyp2[q], act)); }
+    {
+        int lo = 0, hi = 0;
+        HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));   // (lo = the numerically greatest = least urgent)
+        HIPCHK(h, hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, lo));
+        for (int q = 0; q < 2; q++) {
+            HIPCHK(h, hipEventCreateWithFlags(&c->ev_conv[q], hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&c->ev_wg[q], hipEventDisableTiming));
+        }
+    }
     for (int q = 0; q < 2; q++) TRY(dalloc(h, c, &c->af[q], act));
     TRY(dalloc(h, c, &c->pv0, M * 4)); TRY(dalloc(h, c, &c->dpv, M * 4)); TRY(dalloc(h, c, &c->hstat, (size_t)8));
     TRY(dalloc(h, c, &c->fpi, (size_t)BS * 84)); TRY(dalloc(h, c, &c->fv, (size_t)BS * 42)); TRY(dalloc(h, c, &c->h1, (size_t)BS * 256));
@@ -2237,7 +2250,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     const size_t wn = wn_;
     // (t_conv_rs<2, 2, 1>, the backward-data conv of layer l, leaves stage 1 of layer l - 1's batch-norm backward behind: its
     //  block partials are then already in c->part, `fused_parts` blocks of them)
-    int fused_parts = 0;
+    int fused_parts = 0, side_used = 0;
     const bool fuse = sb && g_fuse_bwd;
     for (int l = c->L - 1; l >= 1; l--) {
         // gradient w.r.t. this layer's post-activation output: G for the second conv of a block, DT for the first
@@ -2254,13 +2267,17 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         }
         hipLaunchKernelGGL((t_bn_bwd_finalize<false>), dim3(8), dim3(1024), 0, st, dp ? c->red : c->part, dp ? 1 : Rl, gbn, c->sums, gscale);
         float* dIn = second ? c->DT : c->G;
-        const Parts dyP{{c->dyp[0], c->dyp[1], nullptr}};
         const Parts apP{{Ap(l - 1).p[0], Ap(l - 1).p[1], nullptr}};
         if (fuse && g_fuse_apply) {
             // dY is computed in the backward-data conv's staging path (t_bn_bwd_apply's arithmetic; its two bf16 parts and, where the
             // layer closes a block, dz = the shortcut gradient DS are written out on the way), so that conv runs FIRST and the
-            // weight-gradient GEMM reads the parts it left behind
-            const ProFuse pf{dOut, Al(l), Yl(l), c->mean + l * NF, c->istd + l * NF, bn, c->sums, invM, second ? c->DS : (float*)nullptr, c->dyp[0], c->dyp[1]};
+            // weight-gradient GEMM reads the parts it left behind — on the side stream (TrainCtx::side), from the set of its layer parity
+            const bool beside = convq && !c->native;   // (in-stream RCCL collectives and cross-stream edges do not mix: 16 ms per step measured)
+            const int q = beside ? (l & 1) : 0;
+            uint16_t* const* dq = q ? c->dyp2 : c->dyp;
+            const Parts dyP{{dq[0], dq[1], nullptr}};
+            if (beside && l + 2 <= c->L - 1) HIPCHK(h, hipStreamWaitEvent(st, c->ev_wg[q], 0));   // layer l + 2's weight gradient has read this set
+            const ProFuse pf{dOut, Al(l), Yl(l), c->mean + l * NF, c->istd + l * NF, bn, c->sums, invM, second ? c->DS : (float*)nullptr, dq[0], dq[1]};
             fused_parts = 0;
             const Parts none{{nullptr, nullptr, nullptr}};
             if (l >= 2) {
@@ -2277,10 +2294,24 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
                 else hipLaunchKernelGGL((t_conv_rs<2, 2, 0, false, 2>), dim3((BS + 1) / 2), dim3(256), 0, st, none, Wpb(l), dIn, BS, BwdFuse{}, 1.0f, pf);
                 if (!second) hipLaunchKernelGGL(t_add, dim3(g4), dim3(256), 0, st, dIn, c->DS, act / 4);
             }
-            hipLaunchKernelGGL(t_wgrad_rs, dim3(64 * c->wg_slices), dim3(64), Wg::LDS_BYTES, st, apP, dyP, c->wpart, M, c->wg_slices, c->wg_rows);
-            hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, c->wg_slices, wn, Gl(l));
+            if (!beside) {  // large batches: the chain's kernels and the weight gradient each fill the register files on their own (368 and 280
+                            // VGPRs: no SIMD holds a wave of both) and nothing overlaps: one stream.  (Measured at batch 512: the branch on the
+                            // side stream 11.16 ms per step, only its slice sums there 11.28, one stream 11.1 — a cross-stream edge costs the
+                            // chain a barrier packet per layer, about what hiding the 10-us slice sum saves.)
+                hipLaunchKernelGGL(t_wgrad_rs, dim3(64 * c->wg_slices), dim3(64), Wg::LDS_BYTES, st, apP, dyP, c->wpart, M, c->wg_slices, c->wg_rows);
+                hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, c->wg_slices, wn, Gl(l));
+                continue;
+            }
+            // small batches (a rank's share of a data-parallel minibatch): the chain's kernels leave most of the chip idle, the branch runs beside them
+            HIPCHK(h, hipEventRecord(c->ev_conv[q], st));
+            HIPCHK(h, hipStreamWaitEvent(c->side, c->ev_conv[q], 0));
+            hipLaunchKernelGGL(t_wgrad_rs, dim3(64 * c->wg_slices), dim3(64), Wg::LDS_BYTES, c->side, apP, dyP, c->wpart, M, c->wg_slices, c->wg_rows);
+            hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, c->side, c->wpart, c->wg_slices, wn, Gl(l));
+            HIPCHK(h, hipEventRecord(c->ev_wg[q], c->side));
+            side_used |= 1 << q;
             continue;
         }
+        const Parts dyP{{c->dyp[0], c->dyp[1], nullptr}};
         // (the split-bf16 kernels read the two parts of dY; its fp32 image is only written for the fp32-MFMA GEMMs)
         hipLaunchKernelGGL((t_bn_bwd_apply<false>), dim3(g4), dim3(256), 0, st, dOut, Al(l), Yl(l), c->mean + l * NF, c->istd + l * NF, bn, c->sums,
                            invM, sb ? (float*)nullptr : c->dY, second ? c->DS : (float*)nullptr, M, sb ? c->dyp[0] : nil16, c->dyp[1]);
@@ -2302,6 +2333,8 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         else gemm<false, true, 64, 2, 3>(st, c->dY, KC, Wl(l), NF, dIn, NF, M, NF, KC);
         if (!second) hipLaunchKernelGGL(t_add, dim3(g4), dim3(256), 0, st, dIn, c->DS, act / 4);  // + shortcut gradient
     }
+    // the weight-gradient branch joins: the stem below reuses its split-K buffer, and the gradient vector is complete behind it
+    for (int q = 0; q < 2; q++) if ((side_used >> q) & 1) HIPCHK(h, hipStreamWaitEvent(st, c->ev_wg[q], 0));
     {   // stem: parameters only
         hipLaunchKernelGGL((t_bn_bwd_stats<true>), dim3(R), dim3(1024), 0, st, c->G, Al(0), Yl(0), c->mean, c->istd, M, c->part);
         if (dp) TRY(reduce_parts(2 * NG));
@@ -2323,33 +2356,14 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     return AZR_OK;
 }
 
-// One minibatch step = gather + forward + backward + Adam: ~900 short launches.  Everything that changes from step to
-// step (minibatch offset, Adam step count, learning rate) lives in device memory, so the step can be captured once per
-// context into a hipGraph and replayed (AZR_TRAIN_GRAPH=1).  Measured: 26.0 ms per step either way at B = 20 / batch 512
-// — the ~3 us between consecutive kernels is device-side, not host launch cost — so plain launches are the default.
+// One minibatch step = gather + forward + backward + Adam.  Everything that changes from step to step (minibatch offset, Adam step
+// count, learning rate) lives in device memory; the launches are plain stream launches (replaying the step as a captured hipGraph
+// measured the same: the ~3 us between consecutive kernels is device-side, not host launch cost).
 int run_step(azr_engine* h, TrainCtx* c)
 {
-    static const bool use_graph = getenv("AZR_TRAIN_GRAPH") && atoi(getenv("AZR_TRAIN_GRAPH")) != 0;
     c->step++;
-    if (!use_graph || c->ar || c->native) {   // (host callbacks of the data-parallel step cannot be captured)
-        hipLaunchKernelGGL(t_gather, dim3(c->BS), dim3(64), 0, h->stream, c->rec, c->perm, (const int*)c->cur, c->BS, c->in88, c->pit, c->zt);
-        return train_step(h, c, c->loss + 2);
-    }
-    if (c->graph_rec != c->rec || c->graph_perm != c->perm || c->graph_flat != h->net.d_flat) {  // (re)capture: buffers moved
-        if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
-        if (c->graph) { hipGraphDestroy(c->graph); c->graph = nullptr; }
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        hipLaunchKernelGGL(t_gather, dim3(c->BS), dim3(64), 0, h->stream, c->rec, c->perm, (const int*)c->cur, c->BS, c->in88, c->pit, c->zt);
-        int rc = train_step(h, c, c->loss + 2);
-        hipError_t e = hipStreamEndCapture(h->stream, &c->graph);
-        if (rc) return rc;
-        HIPCHK(h, e);
-        HIPCHK(h, hipGraphInstantiate(&c->gexec, c->graph, nullptr, nullptr, 0));
-        c->graph_rec = c->rec; c->graph_perm = c->perm; c->graph_flat = h->net.d_flat;
-    }
-    HIPCHK(h, hipGraphLaunch(c->gexec, h->stream));
-    return AZR_OK;
+    hipLaunchKernelGGL(t_gather, dim3(c->BS), dim3(64), 0, h->stream, c->rec, c->perm, (const int*)c->cur, c->BS, c->in88, c->pit, c->zt);
+    return train_step(h, c, c->loss + 2);
 }
 
 // after training: device master copy -> host AZRW copy -> refold / repack for inference
