@@ -385,7 +385,8 @@ __device__ __forceinline__ int run_descents(const Dev& E, int g, const Tree& t0,
             uint32_t kd = ws_record_dword(s);
             uint32_t h = key_hash(kd);
             TP(9);
-            uint32_t idx = tree_lookup(t, kd, h);
+            NodeRegs nr;
+            uint32_t idx = tree_lookup_node(t, kd, h, nr);
             TP(10);
             if (idx == NO_NODE) {  // leaf: hand the position to the NN service
                 encode88(s, E.leaf_in + slot * LEAF_STRIDE);
@@ -397,7 +398,7 @@ __device__ __forceinline__ int run_descents(const Dev& E, int g, const Tree& t0,
                 break;
             }
             k.levels++;
-            uint32_t mv = tree_select(t, idx, S, c.search_id, scratch);
+            uint32_t mv = tree_select(t, idx, nr, S, c.search_id, scratch);
             TP(12);
             if (mv == NONE) { fail = true; s.err = E_LOGIC; break; }
             uint32_t before = s.cur;

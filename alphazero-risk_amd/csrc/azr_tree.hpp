@@ -268,21 +268,57 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// the fields of a node the selection reads, one lane per move (lanes >= 43 hold move 0's)
+struct NodeRegs { uint32_t sumN, valid_lo, valid_hi, W; float P, Q; };
+
+__device__ __forceinline__ NodeRegs node_load(const uint8_t* n)
+{
+    const uint32_t l = lane_id(), ll = l < MOVES ? l : 0;
+    NodeRegs r;
+    r.sumN = *reinterpret_cast<const uint32_t*>(n + ND_SUMN);
+    r.valid_lo = *reinterpret_cast<const uint32_t*>(n + ND_VALID_LO);
+    r.valid_hi = *reinterpret_cast<const uint32_t*>(n + ND_VALID_HI);
+    r.P = reinterpret_cast<const float*>(n + ND_P)[ll];
+    r.Q = reinterpret_cast<const float*>(n + ND_Q)[ll];
+    r.W = reinterpret_cast<const uint32_t*>(n + ND_N)[ll];
+    return r;
+}
+
+// tree_lookup for the descent: the node's selection fields are requested together with its key (both hang off the table entry
+// alone), so a hit hands them to tree_select without a second dependent round trip to L2 / HBM — a level of the descent is a chain of
+// such round trips and little else.  A tag collision wastes the six loads; a miss issues none.
+__device__ __forceinline__ uint32_t tree_lookup_node(const Tree& t, uint32_t kd, uint32_t h, NodeRegs& nr)
+{
+    const uint32_t tag = h >> 16;
+    uint32_t slot = h & (uint32_t)(t.H - 1);
+    for (int probes = 0; probes < t.H; probes++) {
+        uint32_t e = rfl(t.table[slot]);
+        if (e == 0) return NO_NODE;
+        if ((e >> 16) == tag) {
+            uint32_t idx = (e & 0xffffu) - 1u;
+            const uint8_t* n = node_ptr(t, idx);
+            uint32_t nk = reinterpret_cast<const uint32_t*>(n)[lane_id() & 15u];
+            nr = node_load(n);
+            if (ballot64(nk != kd) == 0) return idx;
+        }
+        slot = (slot + 1) & (uint32_t)(t.H - 1);
+    }
+    return NO_NODE;
+}
+
 // StateSimulations::getNextBestMoveAndSetVisited (alphazero_mcts.cpp:67-119).  Float ops in the reference's order, no
 // FMA.  The reference's loop keeps the first strict maximum in unordered_map iteration order over the moves that are
 // not "skipped" (N == 0 && active_N == 1: another thread is already exploring that unobserved move); only when every
 // candidate is skipped does it fall back to the best skipped one.  active_N++ on the chosen move.
-__device__ __forceinline__ uint32_t tree_select(const Tree& t, uint32_t idx, const Search& S, uint32_t stamp, int8_t* scratch)
+__device__ __forceinline__ uint32_t tree_select(const Tree& t, uint32_t idx, const NodeRegs& nr, const Search& S, uint32_t stamp, int8_t* scratch)
 {
     const uint8_t* n = node_ptr(t, idx);
     const uint32_t l = lane_id();
-    const uint32_t ll = l < MOVES ? l : 0;
-    const uint32_t sumN = rfl(*reinterpret_cast<const uint32_t*>(n + ND_SUMN));
-    const uint64_t valid = (uint64_t)rfl(*reinterpret_cast<const uint32_t*>(n + ND_VALID_LO)) |
-                           ((uint64_t)rfl(*reinterpret_cast<const uint32_t*>(n + ND_VALID_HI)) << 32);
-    const float P = reinterpret_cast<const float*>(n + ND_P)[ll];
-    const float Q = reinterpret_cast<const float*>(n + ND_Q)[ll];
-    const uint32_t W = reinterpret_cast<const uint32_t*>(n + ND_N)[ll];
+    const uint32_t sumN = rfl(nr.sumN);
+    const uint64_t valid = (uint64_t)rfl(nr.valid_lo) | ((uint64_t)rfl(nr.valid_hi) << 32);
+    const float P = nr.P;
+    const float Q = nr.Q;
+    const uint32_t W = nr.W;
     const uint32_t N = W & N_MASK, act = W >> 24;
     if (l == 0) t.touch[idx] = stamp;  // visited = true
     const float noiseP = __fadd_rn(__fmul_rn(S.c1, P), S.c2);
@@ -303,7 +339,6 @@ __device__ __forceinline__ uint32_t tree_select(const Tree& t, uint32_t idx, con
     wave_mem_sync();
     return mv;
 }
-
 // NNOutputData::normalize (alphazero_nn_data.cpp:3-27): sequential fp32 sum over the legal entries, index order
 __device__ __forceinline__ float normalize_prior(float pi, uint64_t valid)
 {
