@@ -7,7 +7,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-NET_F32, NET_BF16, NET_F32X = 0, 1, 2
+NET_F32, NET_BF16, NET_F32X, NET_F16 = 0, 1, 2, 3
 MOVES, STATE_BYTES, INPUT_BYTES, RECORD_BYTES = 43, 160, 88, 265
 
 

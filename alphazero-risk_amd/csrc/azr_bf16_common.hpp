@@ -7,6 +7,7 @@
 #include "azr_internal.hpp"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -34,6 +35,51 @@ __device__ __forceinline__ uint16_t bf_rne(float f)
 }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
+// The 16-bit element type of a tower: bf16 (AZR_NET_BF16) or fp16 (AZR_NET_F16).  Same kernels, same packed-fragment layout, same MFMA
+// rate (v_mfma_f32_16x16x32_bf16 / _f16); fp16 keeps 11 significand bits instead of 8 — the tower's error against an exact evaluation
+// drops ~9x (tools/net_precision.py) — and pays for it with range: conv weights are packed as 2^k w per layer (the exact inverse goes
+// into the folded BN scale, as for NET_F32X) and activations saturate at 65504 instead of overflowing.
+template <bool F16> struct El;
+template <> struct El<false> {
+    typedef __attribute__((ext_vector_type(2))) __bf16 v2;
+    template <typename TB, typename TA>   // any 16-byte register types (a ring slot is a u32x4, an LDS fragment an s16x8)
+    static __device__ __forceinline__ f32x4 mfma(const TB& b, const TA& a, const f32x4& c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint16_t rne(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+    static __device__ __forceinline__ float tof(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+    // two packed elements (low half first) <-> two floats
+    static __device__ __forceinline__ float lo_of(uint32_t u) { return __uint_as_float(u << 16); }
+    static __device__ __forceinline__ float hi_of(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+    template <typename V2f> static __device__ __forceinline__ uint32_t pack_relu(const V2f& x)   // RNE, then ReLU on the rounded pair
+    {
+        typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+        const s16x2_t z = {0, 0};
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, __builtin_convertvector(x, v2)), z));
+    }
+};
+template <> struct El<true> {
+    typedef __attribute__((ext_vector_type(2))) _Float16 v2;
+    template <typename TB, typename TA>
+    static __device__ __forceinline__ f32x4 mfma(const TB& b, const TA& a, const f32x4& c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, b), __builtin_bit_cast(f16x8_t, a), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint16_t rne(float f) { return __builtin_bit_cast(uint16_t, (_Float16)fminf(f, 65504.0f)); }   // (stem features: once per launch)
+    static __device__ __forceinline__ float tof(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+    static __device__ __forceinline__ float lo_of(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u & 0xffffu)); }
+    static __device__ __forceinline__ float hi_of(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u >> 16)); }
+    template <typename V2f> static __device__ __forceinline__ uint32_t pack_relu(const V2f& x)   // RNE, ReLU and saturation on the rounded pair
+    {
+        // as signed 16-bit integers the non-negative fp16 bit patterns are ordered like their values, +inf = 0x7c00 just above the
+        // largest finite 0x7bff: max with 0 is the ReLU (-0 -> +0), min with 0x7bff the saturation (v_pk_max_i16, v_pk_min_i16)
+        typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+        const s16x2_t z = {0, 0}, m = {0x7bff, 0x7bff};
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(s16x2_t, __builtin_convertvector(x, v2)), z), m));
+    }
+};
+
 // setInStateTensor (alphazero_nn.cpp:31-67) for one cell/plane, from the 88-byte NNInputData image in LDS
 __device__ __forceinline__ float plane_value(const uint8_t* in88, int pos, int c)
 {
@@ -59,6 +105,8 @@ constexpr size_t KBYTES = KSTRIDE * 16;            // bytes per k-step of packed
 constexpr int MAX_RING = 16;                       // deepest weight ring any kernel runs ahead (k-steps): run-off padding
 
 struct Bf16Net {
+    bool f16 = false;                 // AZR_NET_F16: the packed weights and the activations are fp16 (El<true>), `fold16` carries the weight scales
+    float* fold16 = nullptr;          // [14 + 2B * 2 * 256] folded BN with 2^-k of the layer's weight scale in the scale rows
     uint16_t* stem_wp = nullptr;
     uint16_t* tower_wp = nullptr;
     unsigned long long* diag = nullptr;  // set only by azr_debug_tower_clock

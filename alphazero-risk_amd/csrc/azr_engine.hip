@@ -899,6 +899,7 @@ extern "C" int azr_engine_create(const azr_settings* s, azr_engine** out)
     if (!s) return bad("settings is NULL");
     if (s->games <= 0) return bad("games = " + std::to_string(s->games) + " (need > 0)");
     if (s->blocks <= 0) return bad("blocks = " + std::to_string(s->blocks) + " (need > 0)");
+    if (s->net_dtype < AZR_NET_F32 || s->net_dtype > AZR_NET_F16) return bad("net_dtype = " + std::to_string(s->net_dtype) + " (AZR_NET_F32 .. AZR_NET_F16)");
     if (s->mcts_simulations < 0) return bad("mcts_simulations = " + std::to_string(s->mcts_simulations) + " (need >= 0)");
     if (s->mcts_threads < 1 || s->mcts_threads > MAX_THREADS)
         return bad("mcts_threads = " + std::to_string(s->mcts_threads) + " (need 1.." + std::to_string(MAX_THREADS) + ")");
@@ -1400,7 +1401,7 @@ extern "C" int azr_selfplay_run(azr_engine* h, int passes)
     SYNC(h);
     { int rcn = net_check(h); if (rcn) return rcn; }
     double tn = 0, tt = 0, tw = 0;
-    const bool tower_timed = h->cfg.net_dtype == AZR_NET_BF16 || h->cfg.net_dtype == AZR_NET_F32X;   // one kernel = one net forward, bracketed by events
+    const bool tower_timed = h->cfg.net_dtype == AZR_NET_BF16 || h->cfg.net_dtype == AZR_NET_F32X || h->cfg.net_dtype == AZR_NET_F16;   // one kernel = one net forward, bracketed by events
     for (int i = 0; i < k; i++) {
         float a = 0, b = 0, c = 0;
         HIPCHK(h, hipEventElapsedTime(&a, h->ev[3 * i + 0], h->ev[3 * i + 1]));

@@ -31,7 +31,7 @@ using namespace azr;
 namespace azr {
 int net_bf16_alloc(azr_engine* h);
 void net_bf16_free(azr_engine* h);
-int net_bf16_upload(azr_engine* h);
+int net_bf16_upload(azr_engine* h, const float* fold_host);
 int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st);
 }  // namespace azr
 
@@ -343,8 +343,8 @@ int azr::net_upload(azr_engine* h)
     h->net.tower_scale = x->d_fold + 14;
     h->net.tower_shift = x->d_fold + 14 + NF;
     h->net.head = x->d_flat + off_heads(B);
-    if (h->cfg.net_dtype == AZR_NET_BF16) {
-        int rc = net_bf16_upload(h);
+    if (h->cfg.net_dtype == AZR_NET_BF16 || h->cfg.net_dtype == AZR_NET_F16) {
+        int rc = net_bf16_upload(h, fold.data());
         if (rc) return rc;
     }
     if (h->cfg.net_dtype == AZR_NET_F32X) {
@@ -406,7 +406,7 @@ int azr::net_forward_ex(azr_engine* h, const uint8_t* d_in88, int in_stride, int
 namespace azr { int tower_sc_check(azr_engine* h); }   // azr_tower_sc.hip
 int azr::net_check(azr_engine* h)
 {
-    if (h->cfg.net_dtype == AZR_NET_BF16 && h->net.bf16ctx) return tower_sc_check(h);
+    if ((h->cfg.net_dtype == AZR_NET_BF16 || h->cfg.net_dtype == AZR_NET_F16) && h->net.bf16ctx) return tower_sc_check(h);
     return AZR_OK;
 }
 

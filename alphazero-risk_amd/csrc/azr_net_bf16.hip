@@ -563,6 +563,8 @@ int net_bf16_alloc(azr_engine* h)
     Bf16Net* x = new Bf16Net();
     h->net.bf16ctx = x;
     const int B = h->net.blocks;
+    x->f16 = h->cfg.net_dtype == AZR_NET_F16;
+    if (x->f16) HIPCHK(h, hipMalloc((void**)&x->fold16, (14 + (size_t)2 * B * 2 * NF) * sizeof(float)));
     HIPCHK(h, hipMalloc((void**)&x->stem_wp, STEM_HALFS * 2));
     HIPCHK(h, hipMalloc((void**)&x->tower_wp, ((size_t)2 * B * TOWER_LAYER_HALFS + MAX_RING * KSTRIDE * 8) * 2));  // + ring run-off
     HIPCHK(h, hipMemsetAsync(x->tower_wp, 0, ((size_t)2 * B * TOWER_LAYER_HALFS + MAX_RING * KSTRIDE * 8) * 2, h->stream));
@@ -585,18 +587,53 @@ void net_bf16_free(azr_engine* h)
     tower_sc_free(h);
     if (x->stem_wp) hipFree(x->stem_wp);
     if (x->tower_wp) hipFree(x->tower_wp);
+    if (x->fold16) hipFree(x->fold16);
     delete x;
     h->net.bf16ctx = nullptr;
 }
 
-// pack the HWIO fp32 kernels of the AZRW vector into MFMA B-operand fragment order (bf16, RNE):
+// pack the HWIO fp32 kernels of the AZRW vector into MFMA B-operand fragment order (bf16 or fp16, RNE):
 // fragment (layer, tap, ks, wave, nt), lane l, element j  <-  W[tap][ci = ks*32 + 8*(l>>4) + j][co = wave*32 + nt*16 + (l&15)]
-int net_bf16_upload(azr_engine* h)
+
+// power-of-two scale of one fp16-packed weight tensor: max |2^e w| in [2^13, 2^14) (e clipped to [-2, 24]); false = a weight is
+// outside the fp16 range or not a number
+static bool f16_scale(const float* W, size_t n, int& e)
+{
+    float worst = 0.0f;
+    for (size_t i = 0; i < n; i++) {
+        const float aw = W[i] < 0 ? -W[i] : W[i];
+        if (!(aw <= worst)) worst = aw;   // (also catches NaN)
+    }
+    if (!(worst < 65504.0f)) return false;
+    e = 0;
+    if (worst > 0.0f) {
+        int we;
+        frexpf(worst, &we);           // worst = f * 2^we, f in [0.5, 1)
+        e = 14 - we;
+        if (e > 24) e = 24;
+        if (e < -2) e = -2;
+    }
+    return true;
+}
+static inline uint16_t f2h(float f) { const _Float16 v = (_Float16)f; uint16_t u; memcpy(&u, &v, 2); return u; }
+
+// packs the stem and tower conv weights into MFMA fragments: bf16 (NET_BF16), or fp16 of 2^k w with k per layer and 2^-k folded into
+// the layer's BN scale (NET_F16; `fold_host` = the fp32 fold of net_upload)
+int net_bf16_upload(azr_engine* h, const float* fold_host)
 {
     Bf16Net* x = bn(h);
     const int B = h->net.blocks;
+    const bool f16 = x->f16;
     const float* flat = h->flat.data();
     std::vector<uint16_t> stem(STEM_HALFS, 0), tower((size_t)2 * B * TOWER_LAYER_HALFS);
+    std::vector<float> fold(fold_host, fold_host + 14 + (size_t)2 * B * 2 * NF);
+    float sS = 1.0f;
+    if (f16) {
+        int e = 0;
+        if (!f16_scale(flat, (size_t)9 * 13 * NF, e)) { h->err = "NET_F16: a stem weight is outside the fp16 range (|w| must be < 65504) or not a number"; return AZR_E_INVALID_ARGUMENT; }
+        sS = ldexpf(1.0f, e);
+        for (int y = 0; y < 7; y++) fold[y] *= ldexpf(1.0f, -e);
+    }
     for (int ks = 0; ks < STEM_KS; ks++)
         for (int w = 0; w < 8; w++)
             for (int nt = 0; nt < 2; nt++)
@@ -604,12 +641,20 @@ int net_bf16_upload(azr_engine* h)
                     for (int j = 0; j < 8; j++) {
                         const int g = l >> 4, tap = 2 * ks + (g >> 1), ch = (g & 1) * 8 + j, co = w * 32 + nt * 16 + (l & 15);
                         float v = (tap < 9 && ch < 13) ? flat[((size_t)tap * 13 + ch) * NF + co] : 0.0f;
-                        stem[((((size_t)ks * 8 + w) * 2 + nt) * 64 + l) * 8 + j] = f2bf(v);
+                        stem[((((size_t)ks * 8 + w) * 2 + nt) * 64 + l) * 8 + j] = f16 ? f2h(v * sS) : f2bf(v);
                     }
     const size_t layer_floats = (size_t)9 * NF * NF + 4 * NF;
     const float* t0 = flat + 9 * 13 * NF + 28;
     for (int L = 0; L < 2 * B; L++) {
         const float* W = t0 + (size_t)L * layer_floats;
+        float sL = 1.0f;
+        if (f16) {
+            int e = 0;
+            if (!f16_scale(W, (size_t)9 * NF * NF, e)) { h->err = "NET_F16: a conv weight is outside the fp16 range (|w| must be < 65504) or not a number"; return AZR_E_INVALID_ARGUMENT; }
+            sL = ldexpf(1.0f, e);
+            float* fs = fold.data() + 14 + (size_t)L * 2 * NF;
+            for (int i = 0; i < NF; i++) fs[i] *= ldexpf(1.0f, -e);
+        }
         uint16_t* dst = tower.data() + (size_t)L * TOWER_LAYER_HALFS;
         for (int tap = 0; tap < 9; tap++)
             for (int ks = 0; ks < 8; ks++)
@@ -618,11 +663,15 @@ int net_bf16_upload(azr_engine* h)
                         for (int l = 0; l < 64; l++) {
                             const int ci0 = ks * 32 + 8 * (l >> 4), co = w * 32 + nt * 16 + (l & 15);
                             uint16_t* d = dst + (((((size_t)tap * 8 + ks) * 8 + w) * 2 + nt) * 64 + l) * 8;
-                            for (int j = 0; j < 8; j++) d[j] = f2bf(W[((size_t)tap * NF + ci0 + j) * NF + co]);
+                            for (int j = 0; j < 8; j++) {
+                                const float wv = W[((size_t)tap * NF + ci0 + j) * NF + co];
+                                d[j] = f16 ? f2h(wv * sL) : f2bf(wv);
+                            }
                         }
     }
     HIPCHK(h, hipMemcpyAsync(x->stem_wp, stem.data(), stem.size() * 2, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(x->tower_wp, tower.data(), tower.size() * 2, hipMemcpyHostToDevice, h->stream));
+    if (f16) HIPCHK(h, hipMemcpyAsync(x->fold16, fold.data(), fold.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return AZR_OK;
 }
@@ -630,10 +679,10 @@ int net_bf16_upload(azr_engine* h)
 // Single-image tiles (azr_tower_sb.hip) for 2, 3 or 4 boards per workgroup: boards per workgroup for a launch of n boards,
 // or 0 = the two-image kernels (1..3 boards).  AZR_TOWER_SB: 0 = never, 1 = plan (default), 2 / 3 / 4 = force the 4- / 2- /
 // 3-board tile for every launch (tests, measurements).
-static int plan_sb(int sb_mode, int n)
+static int plan_sb(int sb_mode, int n, bool any_n = false)   // any_n: the tile plan for launches of <= 256 boards too (NET_F16 has no one-board kernel)
 {
     int snb = sb_mode == 2 ? 4 : sb_mode == 3 ? 2 : sb_mode == 4 ? 3 : 0;
-    if (sb_mode == 1 && n > 256) {
+    if (snb == 0 && (any_n || (sb_mode == 1 && n > 256))) {
         // Relative time of one 256-workgroup round of 2 / 3 / 4 boards per workgroup.  One workgroup per CU is resident, so a launch
         // of w workgroups takes ceil(w / 256) rounds, and only the RATIOS of the round times enter the choice: the three tiles are
         // the same MFMA-bound code, so a box that clocks lower stretches all three alike.  The ratios are those of the tiles'
@@ -649,7 +698,7 @@ static int plan_sb(int sb_mode, int n)
             if (snb == 0 || t < best) { snb = c; best = t; }
         }
     }
-    return n >= snb ? snb : 0;
+    return (n >= snb || any_n) ? snb : 0;
 }
 
 int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st)
@@ -658,6 +707,16 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
     const float* fold = net_fold(h);
     const int B = h->net.blocks;
     if (h->pe_tower0) hipEventRecord(h->pe_tower0, st);
+    if (x->f16) {   // NET_F16: the split-channel tower up to 128 boards, the single-image tiles above (2 boards per workgroup up to 512)
+        int rc;
+        if (x->sb_mode <= 1 && x->sc_mode != 0 && n <= 128) rc = tower_sc_launch(h, d_in88, in_stride, n, d_pi, d_v, d_map, st);
+        else {
+            const int snb = plan_sb(x->sb_mode, n, true);
+            rc = tower_sb_launch(h, snb, (n + snb - 1) / snb, d_in88, in_stride, n, d_pi, d_v, d_map, st);
+        }
+        if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
+        return rc;
+    }
     if (const int snb = plan_sb(x->sb_mode, n)) {   // more than 256 boards: 2, 3 or 4 per workgroup in one LDS image (azr_tower_sb.hip)
         int rc = tower_sb_launch(h, snb, (n + snb - 1) / snb, d_in88, in_stride, n, d_pi, d_v, d_map, st);
         if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
@@ -705,9 +764,11 @@ static int tower_diag_run(azr_engine* h, int n, int warm, std::vector<unsigned l
 extern "C" int azr_debug_tower_plan(azr_engine* h, int n, int* boards_per_wg, int* wgs)
 {
     if (!h || !h->net.bf16ctx || n < 1) return AZR_E_STATE;
-    const int snb = plan_sb(bn(h)->sb_mode, n);
+    const bool f16 = bn(h)->f16;
+    const bool sc = (f16 ? bn(h)->sb_mode <= 1 : bn(h)->sb_mode != 0) && bn(h)->sc_mode != 0 && n <= 128;
+    const int snb = (f16 && sc) ? 0 : plan_sb(bn(h)->sb_mode, n, f16);
     if (snb) { *boards_per_wg = snb; *wgs = (n + snb - 1) / snb; return AZR_OK; }
-    if (bn(h)->sb_mode != 0 && bn(h)->sc_mode != 0 && n <= 128) {   // split-channel tower: 4 workgroups of 64 channels per board pair
+    if (sc) {   // split-channel tower: 4 workgroups of 64 channels per board pair
         *wgs = ((n + 1) / 2) * 4;
         *boards_per_wg = 2;
         return AZR_OK;

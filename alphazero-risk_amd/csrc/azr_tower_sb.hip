@@ -88,14 +88,13 @@ __device__ __forceinline__ void wait_lgkm()
 
 __device__ __forceinline__ s16x8 lds16(const uint8_t* p) { return *reinterpret_cast<const s16x8*>(p); }
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) short s16x2;
 
 // Layer epilogue for 4 consecutive channels of one board cell: folded BN (fp32 fma), optional shortcut add (the packed
 // bf16 block input), ReLU, round-to-nearest-even to bf16.  Packed forms: v_pk_fma_f32 / v_pk_add_f32 / v_cvt_pk_bf16_f32 /
 // v_pk_max_i16 — ReLU is applied to the ROUNDED value as a signed 16-bit max with 0 (rounding is monotonic and odd, so
 // relu(rne(v)) == rne(relu(v)); -0 becomes +0 like `v > 0 ? v : 0`).
-template <bool SHORTCUT>
+template <bool SHORTCUT, bool F16>
 __device__ __forceinline__ uint2 bn_relu_pack(const f32x4& acc, const float4& s, const float4& h, const uint2& x)
 {
     // (the two instantiations are kept apart on purpose: merged by the optimiser, the common fma of all 44 tiles is hoisted
@@ -106,13 +105,10 @@ __device__ __forceinline__ uint2 bn_relu_pack(const f32x4& acc, const float4& s,
     f32x2 lo = __builtin_elementwise_fma(f32x2{t[0], t[1]}, f32x2{s.x, s.y}, f32x2{h.x, h.y});
     f32x2 hi = __builtin_elementwise_fma(f32x2{t[2], t[3]}, f32x2{s.z, s.w}, f32x2{h.z, h.w});
     if (SHORTCUT) {
-        lo += f32x2{__uint_as_float(x.x << 16), __uint_as_float(x.x & 0xffff0000u)};
-        hi += f32x2{__uint_as_float(x.y << 16), __uint_as_float(x.y & 0xffff0000u)};
+        lo += f32x2{El<F16>::lo_of(x.x), El<F16>::hi_of(x.x)};
+        hi += f32x2{El<F16>::lo_of(x.y), El<F16>::hi_of(x.y)};
     }
-    const s16x2 z = {0, 0};
-    const s16x2 a = __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(lo, bf16x2)), z);
-    const s16x2 b = __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(hi, bf16x2)), z);
-    return uint2{__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b)};
+    return uint2{El<F16>::pack_relu(lo), El<F16>::pack_relu(hi)};
 }
 
 // One tap (8 k-steps of 32 input channels) of a 3x3 conv layer for the 11 row tiles x 4 column tiles of a wave.  Everything
@@ -127,7 +123,7 @@ __device__ __forceinline__ uint2 bn_relu_pack(const f32x4& acc, const float4& s,
 //                  fragment for the next k-step
 // The compiler's own waitcnt insertion still runs afterwards and stays the safety net: an explicit wait only moves a wait
 // to an earlier, cheaper place.
-template <int NB, int TAP>
+template <int NB, int TAP, bool F16>
 __device__ __forceinline__ void conv_tap(const uint8_t* bufX, const uint8_t* tr_c, uint32_t g16, const __amdgpu_buffer_rsrc_t wsrc,
                                          uint32_t loff, uint32_t& wk, u32x4 (&bq)[SB<NB>::RING][NT], f32x4 (&acc)[SB<NB>::MT][NT],
                                          s16x8 (&a)[SB<NB>::MT], uint32_t (&ap)[SB<NB>::MT])
@@ -148,7 +144,7 @@ __device__ __forceinline__ void conv_tap(const uint8_t* bufX, const uint8_t* tr_
         for (int mt = 0; mt < MT; mt++) {
             if (!((sk >> mt) & 1u)) {
                 const int j = __builtin_popcount(~sk & ((1u << mt) - 1u));   // index among the active tiles
-                acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[cur][0]), __builtin_bit_cast(bf16x8, a[mt]), acc[mt][0], 0, 0, 0);
+                acc[mt][0] = El<F16>::mfma(bq[cur][0], a[mt], acc[mt][0]);
                 // refill of the slot the previous k-step freed, RING - 1 k-steps ahead: one of its 4 loads after the first
                 // MFMA of 4 tiles spread over the k-step (also across layer boundaries)
 #pragma unroll
@@ -156,11 +152,11 @@ __device__ __forceinline__ void conv_tap(const uint8_t* bufX, const uint8_t* tr_
                     if (j == ((nt + 1) * active) / NT - 1)
                         bq[ref][nt] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, loff + nt * 1024, (int)(wk + (RING - 1) * KBYTES), 0);
                 __builtin_amdgcn_sched_barrier(0);
-                acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[cur][1]), __builtin_bit_cast(bf16x8, a[mt]), acc[mt][1], 0, 0, 0);
+                acc[mt][1] = El<F16>::mfma(bq[cur][1], a[mt], acc[mt][1]);
                 wait_lgkm<active - 2>();                            // the next tile's fragment was requested `active - 1` reads ago
                 __builtin_amdgcn_sched_barrier(0);
-                acc[mt][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[cur][2]), __builtin_bit_cast(bf16x8, a[mt]), acc[mt][2], 0, 0, 0);
-                acc[mt][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[cur][3]), __builtin_bit_cast(bf16x8, a[mt]), acc[mt][3], 0, 0, 0);
+                acc[mt][2] = El<F16>::mfma(bq[cur][2], a[mt], acc[mt][2]);
+                acc[mt][3] = El<F16>::mfma(bq[cur][3], a[mt], acc[mt][3]);
                 if (ks < KS_PER_TAP - 1) a[mt] = lds16(bufX + ap[mt] + (ks + 1) * 64);
             }
             // the next tap's source rows, dealt out like everything else: one table byte per tile slot two k-steps before
@@ -176,7 +172,7 @@ __device__ __forceinline__ void conv_tap(const uint8_t* bufX, const uint8_t* tr_
     for (int mt = 0; mt < MT; mt++) ap[mt] = np[mt];
 }
 
-template <int NB>
+template <int NB, bool F16>
 __global__ __launch_bounds__(THREADS, 1) void k_tower_sb(const uint8_t* __restrict__ in88, int in_stride, int n,
                                                           const uint16_t* __restrict__ stem_wp, const uint16_t* __restrict__ tower_wp,
                                                           const float* __restrict__ fold, int blocks, const float* __restrict__ hp,
@@ -247,7 +243,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb(const uint8_t* __restri
         float v = 0.0f;
         const int ci = r < ZR ? rowcell[r] : 0xffff;
         if (ci != 0xffff) v = plane_value(in_l + (ci >> 8) * 96, (ci & 15) * 6 + ((ci >> 4) & 15), ch);
-        reinterpret_cast<uint16_t*>(bufF)[i] = bf_rne(v);
+        reinterpret_cast<uint16_t*>(bufF)[i] = El<F16>::rne(v);
     }
     __syncthreads();
 
@@ -279,7 +275,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb(const uint8_t* __restri
                 const s16x8 av = lds16(bufF + row * FROWB + (g & 1) * 16);
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[nt]), __builtin_bit_cast(bf16x8, av), acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = El<F16>::mfma(b[nt], av, acc[mt][nt]);
             }
         }
         // conv_bn over the board ROW (build_graph.py:68 axis=1) + ReLU
@@ -290,7 +286,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb(const uint8_t* __restri
             const float sc = fold[y], sh = fold[7 + y];
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
-                const uint2 o = bn_relu_pack<false>(acc[mt][nt], float4{sc, sc, sc, sc}, float4{sh, sh, sh, sh}, uint2{0, 0});
+                const uint2 o = bn_relu_pack<false, F16>(acc[mt][nt], float4{sc, sc, sc, sc}, float4{sh, sh, sh, sh}, uint2{0, 0});
                 if (mt < RL) resl[(mt * NT + nt) * THREADS] = o; else res[mt < RL ? 0 : mt - RL][nt] = o;
                 if (c < pad_from<NB>(mt)) *reinterpret_cast<uint2*>(bufX + eoff + mt * 16 * ROWB + nt * 32) = o;
             }
@@ -319,15 +315,15 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb(const uint8_t* __restri
                 if (!((sk0 >> mt) & 1u)) a[mt] = lds16(bufX + ap[mt]);
             }
         }
-        conv_tap<NB, 0>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        conv_tap<NB, 1>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        conv_tap<NB, 2>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        conv_tap<NB, 3>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        conv_tap<NB, 4>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        conv_tap<NB, 5>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        conv_tap<NB, 6>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        conv_tap<NB, 7>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        conv_tap<NB, 8>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap<NB, 0, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap<NB, 1, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap<NB, 2, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap<NB, 3, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap<NB, 4, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap<NB, 5, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap<NB, 6, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap<NB, 7, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        conv_tap<NB, 8, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
         // this layer's folded BN scale / shift go through LDS: 2 registers per lane over the k-steps instead of 32 (which the
         // register allocator parked in scratch), written before the barrier, read back 16 bytes at a time after it
         *reinterpret_cast<float2*>(foldl + 2 * tid) = fnext;
@@ -345,7 +341,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb(const uint8_t* __restri
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
                     const uint2 x = mt < RL ? resl[(mt * NT + nt) * THREADS] : res[mt < RL ? 0 : mt - RL][nt];
-                    const uint2 o = bn_relu_pack<true>(acc[mt][nt], sc[nt], sh[nt], x);
+                    const uint2 o = bn_relu_pack<true, F16>(acc[mt][nt], sc[nt], sh[nt], x);
                     if (mt < RL) resl[(mt * NT + nt) * THREADS] = o; else res[mt < RL ? 0 : mt - RL][nt] = o;
                     if (c < pad_from<NB>(mt)) *reinterpret_cast<uint2*>(bufX + eoff + mt * 16 * ROWB + nt * 32) = o;
                 }
@@ -354,7 +350,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb(const uint8_t* __restri
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
-                    const uint2 o = bn_relu_pack<false>(acc[mt][nt], sc[nt], sh[nt], uint2{0, 0});
+                    const uint2 o = bn_relu_pack<false, F16>(acc[mt][nt], sc[nt], sh[nt], uint2{0, 0});
                     if (c < pad_from<NB>(mt)) *reinterpret_cast<uint2*>(bufX + eoff + mt * 16 * ROWB + nt * 32) = o;
                 }
         }
@@ -392,10 +388,10 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb(const uint8_t* __restri
             for (int q = 0; q < NF / 8; q++) {
                 const s16x8 xx = x8[q];
                 const float4 wa = w4[2 * q], wb = w4[2 * q + 1];
-                sacc = fmaf(bf2f((uint16_t)xx[0]), wa.x, sacc); sacc = fmaf(bf2f((uint16_t)xx[1]), wa.y, sacc);
-                sacc = fmaf(bf2f((uint16_t)xx[2]), wa.z, sacc); sacc = fmaf(bf2f((uint16_t)xx[3]), wa.w, sacc);
-                sacc = fmaf(bf2f((uint16_t)xx[4]), wb.x, sacc); sacc = fmaf(bf2f((uint16_t)xx[5]), wb.y, sacc);
-                sacc = fmaf(bf2f((uint16_t)xx[6]), wb.z, sacc); sacc = fmaf(bf2f((uint16_t)xx[7]), wb.w, sacc);
+                sacc = fmaf(El<F16>::tof((uint16_t)xx[0]), wa.x, sacc); sacc = fmaf(El<F16>::tof((uint16_t)xx[1]), wa.y, sacc);
+                sacc = fmaf(El<F16>::tof((uint16_t)xx[2]), wa.z, sacc); sacc = fmaf(El<F16>::tof((uint16_t)xx[3]), wa.w, sacc);
+                sacc = fmaf(El<F16>::tof((uint16_t)xx[4]), wb.x, sacc); sacc = fmaf(El<F16>::tof((uint16_t)xx[5]), wb.y, sacc);
+                sacc = fmaf(El<F16>::tof((uint16_t)xx[6]), wb.z, sacc); sacc = fmaf(El<F16>::tof((uint16_t)xx[7]), wb.w, sacc);
             }
             const float* bnp = ch < 2 ? bnpi : bnv;
             const int nc = ch < 2 ? 2 : 1, kk = ch < 2 ? ch : 0;
@@ -447,28 +443,39 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_sb(const uint8_t* __restri
 
 namespace azr {
 
+template <int NB, bool F16>
+static int sb_attr(azr_engine* h)
+{
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_sb<NB, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, SB<NB>::LDS_BYTES));
+    return AZR_OK;
+}
 int tower_sb_init(azr_engine* h)
 {
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_sb<4>), hipFuncAttributeMaxDynamicSharedMemorySize, SB<4>::LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_sb<3>), hipFuncAttributeMaxDynamicSharedMemorySize, SB<3>::LDS_BYTES));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_sb<2>), hipFuncAttributeMaxDynamicSharedMemorySize, SB<2>::LDS_BYTES));
-    return AZR_OK;
+    int rc = bf16net(h)->f16 ? (sb_attr<4, true>(h) || sb_attr<3, true>(h) || sb_attr<2, true>(h)) : (sb_attr<4, false>(h) || sb_attr<3, false>(h) || sb_attr<2, false>(h));
+    return rc ? AZR_E_HIP : AZR_OK;
+}
+
+template <int NB, bool F16>
+static void sb_go(azr_engine* h, int wgs, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st)
+{
+    Bf16Net* x = bf16net(h);
+    hipLaunchKernelGGL((k_tower_sb<NB, F16>), dim3(wgs), dim3(THREADS), SB<NB>::LDS_BYTES, st, d_in88, in_stride, n, x->stem_wp, x->tower_wp,
+                       F16 ? (const float*)x->fold16 : net_fold(h), h->net.blocks, net_head_params(h), d_pi, d_v, x->diag, d_map);
 }
 
 // `wgs` workgroups of nb (2, 3 or 4) boards: boards [0, n) of the launch (the last workgroup may be partly filled)
 int tower_sb_launch(azr_engine* h, int nb, int wgs, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st)
 {
     if (nb < 2 || nb > 4 || wgs < 1 || (long long)wgs * nb < n) { h->err = "tower_sb_launch: bad tiling"; return AZR_E_INVALID_ARGUMENT; }
-    Bf16Net* x = bf16net(h);
-    if (nb == 4)
-        hipLaunchKernelGGL(k_tower_sb<4>, dim3(wgs), dim3(THREADS), SB<4>::LDS_BYTES, st, d_in88, in_stride, n, x->stem_wp, x->tower_wp, net_fold(h),
-                           h->net.blocks, net_head_params(h), d_pi, d_v, x->diag, d_map);
-    else if (nb == 3)
-        hipLaunchKernelGGL(k_tower_sb<3>, dim3(wgs), dim3(THREADS), SB<3>::LDS_BYTES, st, d_in88, in_stride, n, x->stem_wp, x->tower_wp, net_fold(h),
-                           h->net.blocks, net_head_params(h), d_pi, d_v, x->diag, d_map);
-    else
-        hipLaunchKernelGGL(k_tower_sb<2>, dim3(wgs), dim3(THREADS), SB<2>::LDS_BYTES, st, d_in88, in_stride, n, x->stem_wp, x->tower_wp, net_fold(h),
-                           h->net.blocks, net_head_params(h), d_pi, d_v, x->diag, d_map);
+    if (bf16net(h)->f16) {
+        if (nb == 4) sb_go<4, true>(h, wgs, d_in88, in_stride, n, d_pi, d_v, d_map, st);
+        else if (nb == 3) sb_go<3, true>(h, wgs, d_in88, in_stride, n, d_pi, d_v, d_map, st);
+        else sb_go<2, true>(h, wgs, d_in88, in_stride, n, d_pi, d_v, d_map, st);
+    } else {
+        if (nb == 4) sb_go<4, false>(h, wgs, d_in88, in_stride, n, d_pi, d_v, d_map, st);
+        else if (nb == 3) sb_go<3, false>(h, wgs, d_in88, in_stride, n, d_pi, d_v, d_map, st);
+        else sb_go<2, false>(h, wgs, d_in88, in_stride, n, d_pi, d_v, d_map, st);
+    }
     HIPCHK(h, hipGetLastError());
     return AZR_OK;
 }

@@ -55,7 +55,6 @@ using namespace azr;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) short s16x2;
 
 namespace {
@@ -81,7 +80,7 @@ static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
 __device__ __forceinline__ s16x8 lds16(const uint8_t* p) { return *reinterpret_cast<const s16x8*>(p); }
 
 // k_tower_sb's epilogue, verbatim: folded BN (fp32 fma), optional shortcut add (packed bf16 block input), ReLU on the rounded value
-template <bool SHORTCUT>
+template <bool SHORTCUT, bool F16>
 __device__ __forceinline__ uint2 bn_relu_pack(const f32x4& acc, const float4& s, const float4& h, const uint2& x)
 {
     f32x4 t = acc;
@@ -90,13 +89,10 @@ __device__ __forceinline__ uint2 bn_relu_pack(const f32x4& acc, const float4& s,
     f32x2 lo = __builtin_elementwise_fma(f32x2{t[0], t[1]}, f32x2{s.x, s.y}, f32x2{h.x, h.y});
     f32x2 hi = __builtin_elementwise_fma(f32x2{t[2], t[3]}, f32x2{s.z, s.w}, f32x2{h.z, h.w});
     if (SHORTCUT) {
-        lo += f32x2{__uint_as_float(x.x << 16), __uint_as_float(x.x & 0xffff0000u)};
-        hi += f32x2{__uint_as_float(x.y << 16), __uint_as_float(x.y & 0xffff0000u)};
+        lo += f32x2{El<F16>::lo_of(x.x), El<F16>::hi_of(x.x)};
+        hi += f32x2{El<F16>::lo_of(x.y), El<F16>::hi_of(x.y)};
     }
-    const s16x2 z = {0, 0};
-    const s16x2 a = __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(lo, bf16x2)), z);
-    const s16x2 b = __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(hi, bf16x2)), z);
-    return uint2{__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b)};
+    return uint2{El<F16>::pack_relu(lo), El<F16>::pack_relu(hi)};
 }
 
 // the row tiles of a wave half: 0 - 2 (the board-edge tiles, which skip 3 of their 9 taps each) and 3 - 5.  Uneven on purpose: dealing
@@ -110,7 +106,7 @@ template <int MH> __host__ __device__ constexpr int tile_of(int i) { return MH *
 // at 128 B/clk) and 8 KB through L1 (128 clocks) — with all four waves on all 96 rows it was 24 KB of LDS, 192 clocks, the bound.
 // Everything that is not an MFMA is dealt out one piece per MFMA gap, and scheduling regions (sched_barrier) pin that order: left to
 // itself the compiler sinks the refills until the ring has drained and then runs two loads deep.
-template <int MH, int TAP>
+template <int MH, int TAP, bool F16>
 __device__ __forceinline__ void sc_tap(const uint8_t* bufX, const uint8_t* tr_c, uint32_t g16, const __amdgpu_buffer_rsrc_t wsrc, uint32_t loff, uint32_t wk,
                                        u32x4 (&bq)[RING][NTW], f32x4 (&acc)[MTW][NTW], s16x8 (&a)[MTW], uint32_t (&ap)[MTW])
 {
@@ -126,7 +122,7 @@ __device__ __forceinline__ void sc_tap(const uint8_t* bufX, const uint8_t* tr_c,
             if (!((sk >> i) & 1u)) {
 #pragma unroll
                 for (int nt = 0; nt < NTW; nt++)
-                    acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[cur][nt]), __builtin_bit_cast(bf16x8, a[i]), acc[i][nt], 0, 0, 0);
+                    acc[i][nt] = El<F16>::mfma(bq[cur][nt], a[i], acc[i][nt]);
                 if (ks < KS_PER_TAP - 1) a[i] = lds16(bufX + ap[i] + (ks + 1) * 64);
             }
             if (ks == KS_PER_TAP - 3) { if (!((skn >> i) & 1u)) np[i] = (uint32_t)tr_c[(TAP + 1) * ZR + tile_of<MH>(i) * 16]; }
@@ -209,7 +205,7 @@ __device__ __forceinline__ void gather(uint8_t* bufX, int epoch, int pair, int c
 
 
 // stem + residual tower of one computing wave (row half MH of the pair); false = this workgroup is done (not channel group 0)
-template <int MH>
+template <int MH, bool F16>
 __device__ __forceinline__ bool sc_wave(uint8_t* lds, int pair, int cg, int blocks, const uint16_t* __restrict__ stem_wp, const uint16_t* __restrict__ tower_wp,
                                         uint32_t tower_bytes, const float* __restrict__ fold, uint8_t* __restrict__ ex_base, uint32_t ex_bytes_total,
                                         unsigned* counter, unsigned* err)
@@ -252,7 +248,7 @@ __device__ __forceinline__ bool sc_wave(uint8_t* lds, int pair, int cg, int bloc
                 const s16x8 av = lds16(bufF + row * FROWB + (g & 1) * 16);
 #pragma unroll
                 for (int nt = 0; nt < NTW; nt++)
-                    acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[nt]), __builtin_bit_cast(bf16x8, av), acc[i][nt], 0, 0, 0);
+                    acc[i][nt] = El<F16>::mfma(b[nt], av, acc[i][nt]);
             }
         }
 #pragma unroll
@@ -262,7 +258,7 @@ __device__ __forceinline__ bool sc_wave(uint8_t* lds, int pair, int cg, int bloc
             const float sc = fold[y], sh = fold[7 + y];
 #pragma unroll
             for (int nt = 0; nt < NTW; nt++) {
-                o[i][nt] = bn_relu_pack<false>(acc[i][nt], float4{sc, sc, sc, sc}, float4{sh, sh, sh, sh}, uint2{0, 0});
+                o[i][nt] = bn_relu_pack<false, F16>(acc[i][nt], float4{sc, sc, sc, sc}, float4{sh, sh, sh, sh}, uint2{0, 0});
                 res[i][nt] = o[i][nt];
             }
         }
@@ -297,26 +293,26 @@ __device__ __forceinline__ bool sc_wave(uint8_t* lds, int pair, int cg, int bloc
                 if (!((m0 >> tile_of<MH>(i)) & 1u)) a[i] = lds16(bufX + ap[i]);
             }
         }
-        sc_tap<MH, 0>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        sc_tap<MH, 1>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        sc_tap<MH, 2>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        sc_tap<MH, 3>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        sc_tap<MH, 4>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        sc_tap<MH, 5>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        sc_tap<MH, 6>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        sc_tap<MH, 7>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        sc_tap<MH, 8>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        sc_tap<MH, 0, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        sc_tap<MH, 1, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        sc_tap<MH, 2, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        sc_tap<MH, 3, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        sc_tap<MH, 4, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        sc_tap<MH, 5, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        sc_tap<MH, 6, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        sc_tap<MH, 7, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        sc_tap<MH, 8, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
         wk += (uint32_t)(9 * KS_PER_TAP) * (uint32_t)KBYTES;
         if (L & 1) {    // second conv of a block: + shortcut (the block's input), and this output is the next block's input
 #pragma unroll
             for (int i = 0; i < MTW; i++)
 #pragma unroll
-                for (int nt = 0; nt < NTW; nt++) { o[i][nt] = bn_relu_pack<true>(acc[i][nt], sc[nt], sh[nt], res[i][nt]); res[i][nt] = o[i][nt]; }
+                for (int nt = 0; nt < NTW; nt++) { o[i][nt] = bn_relu_pack<true, F16>(acc[i][nt], sc[nt], sh[nt], res[i][nt]); res[i][nt] = o[i][nt]; }
         } else {
 #pragma unroll
             for (int i = 0; i < MTW; i++)
 #pragma unroll
-                for (int nt = 0; nt < NTW; nt++) o[i][nt] = bn_relu_pack<false>(acc[i][nt], sc[nt], sh[nt], uint2{0, 0});
+                for (int nt = 0; nt < NTW; nt++) o[i][nt] = bn_relu_pack<false, F16>(acc[i][nt], sc[nt], sh[nt], uint2{0, 0});
         }
         publish<MH>(bufX, o, L + 2, pair, ct0, c, g, tid, ex, counter);
         if (L == layers - 1) {
@@ -334,6 +330,7 @@ __device__ __forceinline__ bool sc_wave(uint8_t* lds, int pair, int cg, int bloc
     return true;
 }
 
+template <bool F16>
 __global__ __launch_bounds__(THREADS) void k_tower_sc(const uint8_t* __restrict__ in88, int in_stride, int n, int pairs,
                                                        const uint16_t* __restrict__ stem_wp, const uint16_t* __restrict__ tower_wp, uint32_t tower_bytes,
                                                        const float* __restrict__ fold, int blocks, const float* __restrict__ hp,
@@ -384,7 +381,7 @@ __global__ __launch_bounds__(THREADS) void k_tower_sc(const uint8_t* __restrict_
         float v = 0.0f;
         const int ci = rr < ZR ? rowcell[rr] : 0xffff;
         if (ci != 0xffff) v = plane_value(in_l + (ci >> 8) * 96, (ci & 15) * 6 + ((ci >> 4) & 15), ch);
-        reinterpret_cast<uint16_t*>(bufF)[i] = bf_rne(v);
+        reinterpret_cast<uint16_t*>(bufF)[i] = El<F16>::rne(v);
     }
     // pad rows of the image are MFMA operands of nobody (their tile rows read the zero row) but the image is also fetched whole:
     // keep them defined
@@ -393,8 +390,8 @@ __global__ __launch_bounds__(THREADS) void k_tower_sc(const uint8_t* __restrict_
 
     // ---- stem and tower: waves 0, 1 take the row tiles 0, 3, 4, waves 2, 3 the tiles 1, 2, 5 (the skip masks are compile-time per half)
     unsigned* counter = counters + pair;
-    const bool heads = (wave >> 1) ? sc_wave<1>(lds, pair, cg, blocks, stem_wp, tower_wp, tower_bytes, fold, ex_base, ex_bytes_total, counter, err)
-                                   : sc_wave<0>(lds, pair, cg, blocks, stem_wp, tower_wp, tower_bytes, fold, ex_base, ex_bytes_total, counter, err);
+    const bool heads = (wave >> 1) ? sc_wave<1, F16>(lds, pair, cg, blocks, stem_wp, tower_wp, tower_bytes, fold, ex_base, ex_bytes_total, counter, err)
+                                   : sc_wave<0, F16>(lds, pair, cg, blocks, stem_wp, tower_wp, tower_bytes, fold, ex_base, ex_bytes_total, counter, err);
     if (!heads) return;
 
     // ---- both heads for the pair (k_tower_sb's fused heads), channel group 0 only
@@ -423,10 +420,10 @@ __global__ __launch_bounds__(THREADS) void k_tower_sc(const uint8_t* __restrict_
             for (int q = 0; q < NF / 8; q++) {
                 const s16x8 xx = x8[q];
                 const float4 wa = w4[2 * q], wb = w4[2 * q + 1];
-                sacc = fmaf(bf2f((uint16_t)xx[0]), wa.x, sacc); sacc = fmaf(bf2f((uint16_t)xx[1]), wa.y, sacc);
-                sacc = fmaf(bf2f((uint16_t)xx[2]), wa.z, sacc); sacc = fmaf(bf2f((uint16_t)xx[3]), wa.w, sacc);
-                sacc = fmaf(bf2f((uint16_t)xx[4]), wb.x, sacc); sacc = fmaf(bf2f((uint16_t)xx[5]), wb.y, sacc);
-                sacc = fmaf(bf2f((uint16_t)xx[6]), wb.z, sacc); sacc = fmaf(bf2f((uint16_t)xx[7]), wb.w, sacc);
+                sacc = fmaf(El<F16>::tof((uint16_t)xx[0]), wa.x, sacc); sacc = fmaf(El<F16>::tof((uint16_t)xx[1]), wa.y, sacc);
+                sacc = fmaf(El<F16>::tof((uint16_t)xx[2]), wa.z, sacc); sacc = fmaf(El<F16>::tof((uint16_t)xx[3]), wa.w, sacc);
+                sacc = fmaf(El<F16>::tof((uint16_t)xx[4]), wb.x, sacc); sacc = fmaf(El<F16>::tof((uint16_t)xx[5]), wb.y, sacc);
+                sacc = fmaf(El<F16>::tof((uint16_t)xx[6]), wb.z, sacc); sacc = fmaf(El<F16>::tof((uint16_t)xx[7]), wb.w, sacc);
             }
             const float* bnp = ch < 2 ? bnpi : bnv;
             const int nc = ch < 2 ? 2 : 1, kk = ch < 2 ? ch : 0;
@@ -486,7 +483,8 @@ int tower_sc_init(azr_engine* h)
     HIPCHK(h, hipMemsetAsync(x->sc_ex, 0, ex_bytes, h->stream));
     HIPCHK(h, hipMalloc((void**)&x->sc_counters, (MAX_PAIRS + 4) * sizeof(unsigned)));   // [MAX_PAIRS] arrival counters | error word
     HIPCHK(h, hipMemsetAsync(x->sc_counters, 0, (MAX_PAIRS + 4) * sizeof(unsigned), h->stream));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_sc), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_sc<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_sc<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     return AZR_OK;
 }
 
@@ -511,8 +509,12 @@ int tower_sc_launch(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, 
     const uint32_t ex_bytes = (uint32_t)((size_t)2 * MAX_PAIRS * EX_PAIR_BYTES);
     // the arrival counters count within ONE launch: zeroed ahead of it, in stream order
     HIPCHK(h, hipMemsetAsync(x->sc_counters, 0, MAX_PAIRS * sizeof(unsigned), st));
-    hipLaunchKernelGGL(k_tower_sc, dim3(wgs), dim3(THREADS), LDS_BYTES, st, d_in88, in_stride, n, pairs, x->stem_wp, x->tower_wp, tower_bytes, net_fold(h), B,
-                       net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_counters + MAX_PAIRS);
+    if (x->f16)
+        hipLaunchKernelGGL(k_tower_sc<true>, dim3(wgs), dim3(THREADS), LDS_BYTES, st, d_in88, in_stride, n, pairs, x->stem_wp, x->tower_wp, tower_bytes, (const float*)x->fold16, B,
+                           net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_counters + MAX_PAIRS);
+    else
+        hipLaunchKernelGGL(k_tower_sc<false>, dim3(wgs), dim3(THREADS), LDS_BYTES, st, d_in88, in_stride, n, pairs, x->stem_wp, x->tower_wp, tower_bytes, net_fold(h), B,
+                           net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_counters + MAX_PAIRS);
     HIPCHK(h, hipGetLastError());
     return AZR_OK;
 }

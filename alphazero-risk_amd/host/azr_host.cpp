@@ -70,7 +70,7 @@ void Settings::init(int argc, char* argv[])
         {"ct", "Treshold for accepted improvement", std::to_string(COMPARE_TRESHOLD), false},
         {"s", "Number of stored samples", std::to_string(SAMPLES_STORAGE_MIN), false},
         {"blocks", "[this build] residual blocks of the net (reference: compile-time BLOCKS)", std::to_string(BLOCKS), false},
-        {"dtype", "[this build] net arithmetic bf16|f32x|f32 (f32x = fp32-equivalent on the MFMA)", NET_DTYPE, false},
+        {"dtype", "[this build] net arithmetic bf16|f16|f32x|f32 (f32x = fp32-equivalent on the MFMA)", NET_DTYPE, false},
         {"seed", "[this build] base seed of the per-game RNG streams", std::to_string(BASE_SEED), false},
         {"help", "Display help", "0", true},
     };
@@ -157,7 +157,7 @@ void Settings::toEngine(azr_settings& s, int device) const
     s.device = device;
     s.games = NUMBER_OF_CONCURENT_GAMES_PER_GPU;
     s.blocks = BLOCKS;
-    s.net_dtype = NET_DTYPE == "f32" ? AZR_NET_F32 : NET_DTYPE == "f32x" ? AZR_NET_F32X : AZR_NET_BF16;
+    s.net_dtype = NET_DTYPE == "f32" ? AZR_NET_F32 : NET_DTYPE == "f32x" ? AZR_NET_F32X : NET_DTYPE == "f16" ? AZR_NET_F16 : AZR_NET_BF16;
     s.mcts_simulations = MCTS_SIMULATIONS;
     s.mcts_threads = std::max(1, std::min(8, THREADS_PER_MCTS));
     s.allow_yield = ALLOW_YIELD;

@@ -134,7 +134,7 @@ def reduce_results(gr, dist, dev):
 def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
     os.makedirs("log", exist_ok=True)
     os.makedirs("checkpoints", exist_ok=True)
-    dtype = {"bf16": P.NET_BF16, "f32x": P.NET_F32X, "f32": P.NET_F32}[a.dtype]
+    dtype = {"bf16": P.NET_BF16, "f16": P.NET_F16, "f32x": P.NET_F32X, "f32": P.NET_F32}[a.dtype]
     t = getattr(a, "t", 2)
     if rank != 0:
         log = lambda *_: None   # noqa: E731  (rank 0 reports)
@@ -290,7 +290,7 @@ def main():
     ap.add_argument("--ct", type=float, default=0.55)
     ap.add_argument("-s", type=int, default=1024 * 512)   # SAMPLES_STORAGE_MIN
     ap.add_argument("--seed", type=int, default=20260001)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32x", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32x", "f32"])
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--include-compare-samples", type=int, default=1)   # INCLUDE_COMPARE_GAMES_TRAIN_SAMPLES
     ap.add_argument("--dp", type=int, default=-1,

@@ -199,7 +199,7 @@ def run_config(ctx, games, sims, threads, steps, warmup, tail, dtype=None, midga
     rank, world, local, dev, cdev = ctx["rank"], ctx["world"], ctx["local"], ctx["dev"], ctx["cdev"]
     use_dist = ctx["use_dist"]   # world > 1, or AZR_FORCE_DIST=1: a one-rank world still goes through every collective
     passes_per_step = sims // threads + 1   # setRootState's root expansion + (S - S % T) / T lock-stepped rounds
-    eng = pkg.Engine(games, blocks=a.blocks, sims=sims, dtype={"bf16": pkg.NET_BF16, "f32": pkg.NET_F32, "f32x": pkg.NET_F32X}[dtype],
+    eng = pkg.Engine(games, blocks=a.blocks, sims=sims, dtype={"bf16": pkg.NET_BF16, "f16": pkg.NET_F16, "f32": pkg.NET_F32, "f32x": pkg.NET_F32X}[dtype],
                      device=local, threads=threads)
     eng.init_random(20260002)
     phases = None
@@ -214,10 +214,11 @@ def run_config(ctx, games, sims, threads, steps, warmup, tail, dtype=None, midga
     if dtype == "f32x":
         tower_kernel_name = (f"k_tower_fx<2> x {(games * threads + 1) // 2} workgroups of 2 boards (one whole net forward at fp32-equivalent precision: "
                              "fp16-pair operands, 3 MFMA passes per conv layer, fp32 accumulate / epilogue / residual / heads, one launch)")
-    if dtype == "bf16":   # the tile plan of this configuration's launches (G x T leaf slots), from the library itself
+    if dtype in ("bf16", "f16"):   # the tile plan of this configuration's launches (G x T leaf slots), from the library itself
         nb, wgs = eng.tower_plan(games * threads)
         tower_kernel_name = (f"k_tower_sb<{nb}>" if nb > 1 else "k_tower_bf16<1>") + \
-            f" x {wgs} workgroups of {nb} board(s) (one whole net forward of the G x T leaf slots: stem + 2B conv layers + both heads, one launch)"
+            f" x {wgs} workgroups of {nb} board(s) (one whole net forward of the G x T leaf slots: stem + 2B conv layers + both heads, one launch" + \
+            (", fp16 operands)" if dtype == "f16" else ")")
 
     def barrier():
         torch.cuda.synchronize()
@@ -371,8 +372,8 @@ def main():
     ap.add_argument("--threads", type=int, default=2,
                     help="THREADS_PER_MCTS (-t): search threads per game; 2 is the reference's default (src/settings.h:44)")
     ap.add_argument("--blocks", type=int, default=20)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32x"],
-                    help="bf16 (the benchmarked tower) | f32x (fp32-equivalent fp16-pair MFMA tower) | f32 (fp32 VALU kernels)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32", "f32x"],
+                    help="bf16 (the benchmarked tower) | f16 (the same kernels on fp16 operands) | f32x (fp32-equivalent fp16-pair MFMA tower) | f32 (fp32 VALU kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip BASELINE configs[1] / configs[2] (N = 1 runs them by default)")
     ap.add_argument("--no-full-games", action="store_true",
@@ -444,6 +445,10 @@ def main():
         if a.dtype == "bf16":   # the north-star point again at the reference's precision (it evaluates in fp32, alphazero_nn.cpp:247-248)
             k = max(2, a.steps // 4)
             e = run_config(ctx, a.games, a.sims, a.threads, k, max(1, a.warmup // 4), tail=False, dtype="f32x")
+            e["metric"], e["unit"] = "MCTS simulations/s", "simulations/s"
+            extras.append(e)
+            # ... and on fp16 operands: the bf16 tower's kernels and rate, ~9x closer to the fp32 evaluation (AZR_NET_F16)
+            e = run_config(ctx, a.games, a.sims, a.threads, a.steps, a.warmup, tail=False, dtype="f16")
             e["metric"], e["unit"] = "MCTS simulations/s", "simulations/s"
             extras.append(e)
     if rank == 0:

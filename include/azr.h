@@ -46,15 +46,18 @@ enum {
  *   AZR_NET_F32   fp32 on the vector ALU: the precise, slow path (tolerance anchor of the tests)
  *   AZR_NET_F32X  fp32-equivalent on the MFMA: every conv operand as an fp16 pair (22 significand bits), three MFMA passes
  *                 per layer, fp32 accumulate / epilogue / residual / heads — the reference evaluates in fp32
- *                 (alphazero_nn.cpp:247-248); <= 2e-5 of the fp32 evaluation.  Conv weights must lie in the fp16 range. */
-enum { AZR_NET_F32 = 0, AZR_NET_BF16 = 1, AZR_NET_F32X = 2 };
+ *                 (alphazero_nn.cpp:247-248); <= 2e-5 of the fp32 evaluation.  Conv weights must lie in the fp16 range.
+ *   AZR_NET_F16   fp16 operands on the MFMA (the kernels and the rate of AZR_NET_BF16, 11 significand bits instead of 8): ~9x
+ *                 closer to the fp32 evaluation than bf16 (<= 3e-3).  Conv weights must lie in the fp16 range (they are packed
+ *                 as 2^k w per layer); activations saturate at 65504. */
+enum { AZR_NET_F32 = 0, AZR_NET_BF16 = 1, AZR_NET_F32X = 2, AZR_NET_F16 = 3 };
 
 /* Mirrors the fields of `class Settings` the hot path reads (src/settings.h:41-64) + engine sizing. */
 typedef struct azr_settings {
     int32_t device;                /* HIP device ordinal */
     int32_t games;                 /* G: concurrent games on this handle (gpu-games, settings.h:163-171) */
     int32_t blocks;                /* residual blocks B (CMakeLists.txt:15 BLOCKS, 20) */
-    int32_t net_dtype;             /* AZR_NET_F32 | AZR_NET_BF16 */
+    int32_t net_dtype;             /* AZR_NET_F32 | AZR_NET_BF16 | AZR_NET_F32X | AZR_NET_F16 */
     int32_t mcts_simulations;      /* MCTS_SIMULATIONS (--mcts) */
     int32_t mcts_threads;          /* THREADS_PER_MCTS (-t, settings.h:44; default 2): T lock-stepped search threads per
                                       game with the reference's active_N virtual loss; 1..8.  Leaf slots = games * T. */

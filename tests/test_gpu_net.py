@@ -223,6 +223,60 @@ def test_tile_shapes_agree_bit_for_bit(monkeypatch, blocks):
         assert (out["0"][1].view(np.uint32) == out[mode][1].view(np.uint32)).all(), mode
 
 
+@pytest.mark.parametrize("n,blocks", [(48, 2), (130, 2), (300, 2), (600, 1), (1100, 1), (16, 20)])
+def test_f16_tower_matches_fp32_oracle(orc, n, blocks):
+    """NET_F16: the bf16 tower's kernels on fp16 operands (El<true> in csrc/azr_bf16_common.hpp: same MFMA rate, 11 significand bits;
+    conv weights packed as 2^k w per layer with 2^-k in the folded BN scale).  Stated tolerance: max |d pi|, |d v| <= 3e-3 of the fp32
+    oracle (bf16: 2e-2).  n selects the tile: up to 128 boards the split-channel tower, above that 2, 3 or 4 boards per workgroup."""
+    P = pkg()
+    base = sample_inputs(64)
+    x = np.concatenate([base] * ((n + 63) // 64))[:n].copy()
+    flat = T.make_net_flat(blocks, seed=3, perturb_bn=True)
+    eng = P.Engine(n, blocks=blocks, sims=1, dtype=P.NET_F16, node_capacity=64)
+    eng.set_weights(flat)
+    pi, v = eng.predict(x)
+    m = min(n, 64)
+    rpi, rv = oracle_forward(orc, flat, blocks, x[:m])
+    dpi, dv = np.abs(pi[:m] - rpi).max(), np.abs(v[:m] - rv).max()
+    print(f"f16 n={n} B={blocks}: max|dpi|={dpi:.2e} max|dv|={dv:.2e}")
+    assert dpi <= 3e-3 and dv <= 3e-3, (dpi, dv)
+    assert np.allclose(pi.sum(1), 1.0, atol=1e-5)
+    for k in range(64, n - 63, 64):   # identical inputs in other slots / workgroups: identical bits
+        assert (pi[:64].view(np.uint32) == pi[k:k + 64].view(np.uint32)).all(), k
+        assert (v[:64] == v[k:k + 64]).all(), k
+    p1, v1 = eng.predict(x[:3])
+    assert (p1.view(np.uint32) == pi[:3].view(np.uint32)).all() and (v1 == v[:3]).all()
+    eng.close()
+
+
+def test_f16_tile_shapes_agree_bit_for_bit(monkeypatch):
+    """NET_F16 at the bench's depth: the plan (split-channel tower up to 128 boards, 2 / 3 / 4 boards per workgroup above) and the
+    forced 4- / 2- / 3-board tiles compute the same bits, full and ragged batches; weights outside the fp16 range are refused"""
+    P = pkg()
+    n, blocks = 1024, 20
+    g = np.unique(np.load(os.path.join(T.GOLDEN, "encode.npz"))["in88"], axis=0)
+    x = g[np.linspace(0, len(g) - 1, n).astype(int)].copy()
+    flat = T.make_net_flat(blocks, seed=3, perturb_bn=True)
+    out = {}
+    for mode in ("1", "2", "3", "4"):
+        monkeypatch.setenv("AZR_TOWER_SB", mode)
+        eng = P.Engine(n, blocks=blocks, sims=1, dtype=P.NET_F16, node_capacity=64)
+        eng.set_weights(flat)
+        out[mode] = eng.predict(x)
+        for m in (1023, 700, 400, 256, 201, 129, 128, 113, 64, 17, 2, 1):
+            pm, vm = eng.predict(x[:m])
+            assert (pm.view(np.uint32) == out[mode][0][:m].view(np.uint32)).all() and (vm == out[mode][1][:m]).all(), (mode, m)
+        if mode == "1":
+            bad = flat.copy()
+            bad[9 * 13 * 256 + 28 + 5] = 1e5
+            with pytest.raises(Exception):
+                eng.set_weights(bad)
+        eng.close()
+    for mode in ("2", "3", "4"):
+        assert (out["1"][0].view(np.uint32) == out[mode][0].view(np.uint32)).all(), mode
+        assert (out["1"][1].view(np.uint32) == out[mode][1].view(np.uint32)).all(), mode
+
+
 def oracle_search(orc, flat, blocks, sims, states, seeds, threads=16):
     """the oracle's own search (oracle/azr_oracle.c, THREADS_PER_MCTS 1) on its own fp32 CPU net for every root: visit counts
     [n, 43] and the argmax-N move.  One OS thread per root in flight (the C calls release the GIL)."""
@@ -273,7 +327,7 @@ def test_search_move_agreement_by_net_precision(orc):
     flat = T.make_net_flat(blocks, seed=20260002)
     seeds = np.arange(500, 500 + G, dtype=np.uint32)
     out = {}
-    for name, dt in (("bf16", P.NET_BF16), ("f32x", P.NET_F32X), ("f32", P.NET_F32)):
+    for name, dt in (("bf16", P.NET_BF16), ("f16", P.NET_F16), ("f32x", P.NET_F32X), ("f32", P.NET_F32)):
         eng = P.Engine(G, blocks=blocks, sims=sims, dtype=dt, threads=1)
         eng.set_weights(flat)
         eng.set_states(states)
@@ -305,6 +359,8 @@ def test_search_move_agreement_by_net_precision(orc):
     floor = compare("f32", "oracle")
     fx_o = compare("f32x", "oracle")
     fx_f = compare("f32x", "f32")
+    h_o = compare("f16", "oracle")
+    h_f = compare("f16", "f32")
     bf_o = compare("bf16", "oracle")
     bf_f = compare("bf16", "f32")
     # the benchmarked bf16 tower (measured on MI355X, round 2: 0.958 identical vs NET_F32 over the 96 roots, 0.912 on the clear ones)
@@ -313,6 +369,8 @@ def test_search_move_agreement_by_net_precision(orc):
     # closer than bf16
     assert fx_o[0] >= floor[0] - 0.03 and fx_o[2] <= floor[2] + 0.01, (fx_o, floor)
     assert fx_f[2] <= bf_f[2], (fx_f, bf_f)
+    # fp16 operands: the bf16 tower's kernels and rate, closer to the fp32 search than bf16
+    assert h_f[0] >= bf_f[0] and h_f[2] <= bf_f[2], (h_f, bf_f)
 
 
 def test_selfplay_bf16_runs_clean():

@@ -82,13 +82,14 @@ def test_learn_mode_generates_reference_format_samples(exe, tmp_path):
 
 @pytest.mark.gpu
 def test_play_mode_az_vs_az(exe, tmp_path):
-    r = subprocess.run([exe, "-m", "play", "--p1=az", "--p2=az", "--mcts=4", "--gpu-games=8", "--blocks=1", "--cg=8"],
-                       cwd=tmp_path, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr
-    tail = r.stdout.strip().split("\n")[-4:]
-    assert tail[0] == "Games: 8"
-    d, p1, p2 = (int(t.split(":")[1]) for t in tail[1:])
-    assert d + p1 + p2 == 8
+    for extra in ([], ["--dtype=f16"]):   # (the default bf16 tower, and the same kernels on fp16 operands)
+        r = subprocess.run([exe, "-m", "play", "--p1=az", "--p2=az", "--mcts=4", "--gpu-games=8", "--blocks=1", "--cg=8"] + extra,
+                           cwd=tmp_path, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        tail = r.stdout.strip().split("\n")[-4:]
+        assert tail[0] == "Games: 8"
+        d, p1, p2 = (int(t.split(":")[1]) for t in tail[1:])
+        assert d + p1 + p2 == 8
 
 
 @pytest.mark.gpu

@@ -59,11 +59,11 @@ def write_log(path, rows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--blocks", type=int, default=20)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32x", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32x", "f32"])
     ap.add_argument("--out", default="log/batch-size-perf.txt")
     a = ap.parse_args()
     P = importlib.import_module("alphazero-risk_amd")
-    dt = {"bf16": P.NET_BF16, "f32x": P.NET_F32X, "f32": P.NET_F32}[a.dtype]
+    dt = {"bf16": P.NET_BF16, "f16": P.NET_F16, "f32x": P.NET_F32X, "f32": P.NET_F32}[a.dtype]
     rows = measure(P, a.blocks, dt)
     write_log(a.out, rows)
     print(json.dumps({"file": a.out, "blocks": a.blocks, "dtype": a.dtype, "unit": "ns per sample (azr_nn_predict wall time / batch)",

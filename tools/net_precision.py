@@ -37,7 +37,7 @@ def main():
     opi, ov = np.zeros((len(x), 43), np.float32), np.zeros(len(x), np.float32)
     orc.orc_net_forward_mt(C.byref(net), T.ptr(x), len(x), T.ptr(opi), T.ptr(ov), 16)
     rows = [("oracle fp32 (CPU)", opi, ov)]
-    for name, dt in (("NET_F32  (VALU)", P.NET_F32), ("NET_F32X (fp16 pairs)", P.NET_F32X), ("NET_BF16", P.NET_BF16)):
+    for name, dt in (("NET_F32  (VALU)", P.NET_F32), ("NET_F32X (fp16 pairs)", P.NET_F32X), ("NET_F16", P.NET_F16), ("NET_BF16", P.NET_BF16)):
         eng = P.Engine(len(x), blocks=blocks, sims=1, dtype=dt, node_capacity=64)
         eng.set_weights(flat)
         pi, v = eng.predict(x)
