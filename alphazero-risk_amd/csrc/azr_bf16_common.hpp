@@ -37,7 +37,7 @@ __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint
 
 // The 16-bit element type of a tower: bf16 (AZR_NET_BF16) or fp16 (AZR_NET_F16).  Same kernels, same packed-fragment layout, same MFMA
 // rate (v_mfma_f32_16x16x32_bf16 / _f16); fp16 keeps 11 significand bits instead of 8 — the tower's error against an exact evaluation
-// drops ~9x (tools/net_precision.py) — and pays for it with range: conv weights are packed as 2^k w per layer (the exact inverse goes
+// drops ~7x (tools/net_precision.py) — and pays for it with range: conv weights are packed as 2^k w per layer (the exact inverse goes
 // into the folded BN scale, as for NET_F32X) and activations saturate at 65504 instead of overflowing.
 template <bool F16> struct El;
 template <> struct El<false> {

@@ -47,7 +47,7 @@ enum {
  *   AZR_NET_F32X  fp32-equivalent on the MFMA: every conv operand as an fp16 pair (22 significand bits), three MFMA passes
  *                 per layer, fp32 accumulate / epilogue / residual / heads — the reference evaluates in fp32
  *                 (alphazero_nn.cpp:247-248); <= 2e-5 of the fp32 evaluation.  Conv weights must lie in the fp16 range.
- *   AZR_NET_F16   fp16 operands on the MFMA (the kernels and the rate of AZR_NET_BF16, 11 significand bits instead of 8): ~9x
+ *   AZR_NET_F16   fp16 operands on the MFMA (the kernels and the rate of AZR_NET_BF16, 11 significand bits instead of 8): ~7x
  *                 closer to the fp32 evaluation than bf16 (<= 3e-3).  Conv weights must lie in the fp16 range (they are packed
  *                 as 2^k w per layer); activations saturate at 65504. */
 enum { AZR_NET_F32 = 0, AZR_NET_BF16 = 1, AZR_NET_F32X = 2, AZR_NET_F16 = 3 };
