@@ -5,7 +5,9 @@ Headline workload = the point BASELINE.json's north_star quotes the metric on: 5
 GPU, 100 MCTS simulations per move, THREADS_PER_MCTS 2 (the reference's default, src/settings.h:44), random-init
 20-block / 256-filter net, bf16 MFMA contractions with fp32 accumulation.  At N = 1 the other two single-GPU
 configurations of BASELINE.json (configs[1] 256 x 100 and configs[2] 2048 x 400) run in the same invocation and are
-reported under "extra_configs", each with its own roofline.
+reported under "extra_configs", each with its own roofline (+ the headline point on NET_F32X and NET_F16); "midgame_leg" = the headline
+entered in the middle of games; "config0_play" = BASELINE configs[0] through the host CLI; "optimiser_step" and "arena_100" = the other
+two legs of a learn iteration at their stated shapes (batch 512; 100 mirrored games).
 
 One "step" = one MOVE's worth of the hot path for every game of the batch: S/T + 1 passes, a pass being one tree step
 (expand + backup of the previous leaves, PUCT descents to the next leaves — and, when a search completes, the move,
@@ -190,6 +192,49 @@ def config0_play(blocks):
                 "note": "random-init net; the reference's own CPU run of this command with its _DEBUG random-NN fake took 3.4 s (BASELINE.md §2)"}
     except Exception as e:   # noqa: BLE001  (a missing compiler on the box must not cost the headline)
         return {"error": repr(e)[-300:]}
+
+
+def optimiser_step_leg(pkg, blocks, bs=512, batches=10, epochs=12):
+    """the native optimiser step (azr_nn_train) at the reference's training shape (BATCH_SIZE 512, settings.h:74; learn loop row f-2):
+    `batches` minibatches of self-play records x `epochs` in one call (120 steps: the call's fixed part — record upload, the refold /
+    repack of the weights for inference afterwards — is ~1 % of it), ms per minibatch step"""
+    import numpy as np
+    eng = pkg.Engine(64, blocks=blocks, sims=8, dtype=pkg.NET_BF16)
+    eng.init_random(1)
+    eng.selfplay_start(7)
+    recs = []
+    while sum(len(r) for r in recs) < bs * batches:
+        eng.selfplay_run(64)
+        recs.append(eng.drain())
+    rec = np.concatenate(recs)[:bs * batches]
+    eng.train(rec[:bs], 1, batch_size=bs, rng_state=1)   # allocate + warm up
+    t0 = time.perf_counter()
+    hist, _ = eng.train(rec, epochs, batch_size=bs, rng_state=1)
+    dt = time.perf_counter() - t0
+    eng.close()
+    steps = epochs * batches
+    return {"ms_per_step": 1e3 * dt / steps, "steps": steps, "batch": bs, "blocks": blocks,
+            "what": "azr_nn_train: gather + forward + backward + Adam of one minibatch of 265-byte records, fp32-equivalent split arithmetic on the MFMA",
+            "last_epoch_losses": [float(x) for x in hist[-1]]}
+
+
+def arena_leg(pkg, blocks, games=100, slots=128, sims=100, threads=2):
+    """the learn loop's new-vs-old comparison (GameGroup::playGames with two AlphaZero players and two networks, game.cpp:277-312;
+    alphazero_trainer.cpp:147-152) on the device: wall time of `games` mirrored games"""
+    new = pkg.Engine(slots, blocks=blocks, sims=sims, dtype=pkg.NET_BF16, threads=threads)
+    old = pkg.Engine(slots, blocks=blocks, sims=sims, dtype=pkg.NET_BF16, threads=threads)
+    new.init_random(1)
+    old.init_random(2)
+    new.arena_set_opponent(old)
+    new.arena_start(pkg.PLAYER_ALPHAZERO, pkg.PLAYER_ALPHAZERO_B, games, 0, True, 20260001)
+    t0 = time.perf_counter()
+    while not new.arena_run(256):
+        pass
+    dt = time.perf_counter() - t0
+    r = new.arena_results()
+    new.close(); old.close()
+    return {"wall_s": dt, "games": games, "slots": slots, "sims_per_move": sims, "mcts_threads": threads, "blocks": blocks, "results": r,
+            "what": "two-net arena: 50 mirrored pairs, each pair's two games one after the other on one slot; launches of <= 128 leaves (k_tower_sc)"}
 
 
 def run_config(ctx, games, sims, threads, steps, warmup, tail, dtype=None, midgame=False):
@@ -465,6 +510,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.blocks, a.sims, a.threads)
         if world == 1 and not a.no_extra:
             out["config0_play"] = config0_play(a.blocks)
+            # the two other legs of the reference's learn iteration, each at its stated shape, ~12 s together
+            out["optimiser_step"] = optimiser_step_leg(pkg, a.blocks)
+            out["arena_100"] = arena_leg(pkg, a.blocks)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
