@@ -277,6 +277,43 @@ def test_f16_tile_shapes_agree_bit_for_bit(monkeypatch):
         assert (out["1"][1].view(np.uint32) == out[mode][1].view(np.uint32)).all(), mode
 
 
+def test_split_channel_tower_under_contention(monkeypatch):
+    """k_tower_sc's hand-off (write-through stores + arrival counter between the four workgroups of a board pair) under load: three
+    engines evaluate at the same time from three host threads — two on the split-channel tower, one on one board per workgroup
+    (AZR_TOWER_SC=0, read at creation) — batches of every size up to 128, so launches share CUs, start in the middle of each other and
+    leave groups of pairs partly filled.  Every result must equal the reference engine's bits for the same boards."""
+    from concurrent.futures import ThreadPoolExecutor
+    P = pkg()
+    blocks = 20
+    g = np.unique(np.load(os.path.join(T.GOLDEN, "encode.npz"))["in88"], axis=0)
+    x = g[np.linspace(0, len(g) - 1, 128).astype(int)].copy()
+    flat = T.make_net_flat(blocks, seed=3, perturb_bn=True)
+    monkeypatch.setenv("AZR_TOWER_SC", "0")
+    ref = P.Engine(128, blocks=blocks, sims=1, dtype=P.NET_BF16, node_capacity=64)
+    monkeypatch.setenv("AZR_TOWER_SC", "1")
+    engs = [P.Engine(128, blocks=blocks, sims=1, dtype=P.NET_BF16, node_capacity=64) for _ in range(2)]
+    for e in [ref] + engs:
+        e.set_weights(flat)
+    want_pi, want_v = ref.predict(x)
+    assert ref.tower_plan(100)[0] == 1 and engs[0].tower_plan(100) == (2, 200)   # one board per workgroup / 50 pairs x 4 workgroups
+
+    def hammer(k):
+        e = ([ref] + engs)[k]
+        rng = np.random.default_rng(k)
+        bad = 0
+        for it in range(150):
+            m = int(rng.integers(1, 129))
+            o = int(rng.integers(0, 129 - m))
+            pi, v = e.predict(x[o:o + m])
+            bad += not ((pi.view(np.uint32) == want_pi[o:o + m].view(np.uint32)).all() and (v == want_v[o:o + m]).all())
+        return bad
+
+    with ThreadPoolExecutor(3) as ex:
+        assert list(ex.map(hammer, range(3))) == [0, 0, 0]
+    for e in [ref] + engs:
+        e.close()
+
+
 def oracle_search(orc, flat, blocks, sims, states, seeds, threads=16):
     """the oracle's own search (oracle/azr_oracle.c, THREADS_PER_MCTS 1) on its own fp32 CPU net for every root: visit counts
     [n, 43] and the argmax-N move.  One OS thread per root in flight (the C calls release the GIL)."""
