@@ -21,9 +21,10 @@
 //     word and the launch ends with garbage, never hangs), workgroup barrier, the partners' channels are fetched with sc1 loads
 //     (they never hit this CU's L1: no acquire fence needed for write-through, drained stores) into the LDS image, barrier.
 // (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility": the drained-sc1-stores + counter form.)
-// 3.2 us per layer.  Tried and left out (profiles/r03_small_batch_tower.txt): a data-is-the-flag form (epoch tag in the sign bits of
+// 3.2 us per layer; where the four workgroups of a pair run on one XCD (checked at run time through HW_REG_XCC_ID; the block ids are laid
+// out for it) the layer images stay in that XCD's L2 — plain stores instead of write-through ones, 3 - 4 % of a launch.  Tried and left out (profiles/r03_small_batch_tower.txt): a data-is-the-flag form (epoch tag in the sign bits of
 // the post-ReLU bf16, no drain / counter / poll) — 4.1 us, the first sweep always comes too early and a sweep is a full round trip;
-// plain stores for same-XCD partners — 5 % of the pass; a fifth wave touching the next layers' weights into L2 — slower, the L1
+// a fifth wave touching the next layers' weights into L2 — slower, the L1
 // path is the bound and the touches double its traffic.
 // Exchange images are double-buffered by layer parity: to overwrite parity p a workgroup must have finished layer L + 1, which
 // needed every partner's layer-L + 1 slice, which they produced after reading layer L — no reader can be behind.  All workgroups of
@@ -59,6 +60,7 @@ typedef __attribute__((ext_vector_type(2))) short s16x2;
 
 namespace {
 constexpr int NB = 2, ROWS = 84, MT = 6, ZR = 96, THREADS = 256;
+constexpr int MAX_PAIRS = 64;                        // board pairs of one launch (128 boards)
 constexpr int CGN = 4;                                // workgroups per board pair: 64 output channels each
 constexpr int MTW = 3, NTW = 2;                       // a wave's tile: 3 row tiles (one half of the pair's 96 rows) x 2 column tiles (32 channels)
 constexpr int RING = 12;                              // weight ring depth in k-steps (72 = 0 mod RING): 22 KB in flight per wave
@@ -146,7 +148,7 @@ __device__ __forceinline__ void sc_tap(const uint8_t* bufX, const uint8_t* tr_c,
 // the old one any more).
 template <int MH>
 __device__ __forceinline__ void publish(uint8_t* bufX, const uint2 (&o)[MTW][NTW], int epoch, int pair, int ct0, int c, int g, int tid,
-                                        const __amdgpu_buffer_rsrc_t ex, unsigned* counter)
+                                        const __amdgpu_buffer_rsrc_t ex, unsigned* counter, bool same_xcd)
 {
     const uint32_t img_off = (uint32_t)(pair * 2 + (epoch & 1)) * EX_PAIR_BYTES;
 #pragma unroll
@@ -156,7 +158,10 @@ __device__ __forceinline__ void publish(uint8_t* bufX, const uint2 (&o)[MTW][NTW
 #pragma unroll
         for (int nt = 0; nt < NTW; nt++) {
             const uint32_t off = img_off + (uint32_t)((mt * 16 + c) * NF + (ct0 + nt) * 16 + g * 4) * 2u;
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{o[i][nt].x, o[i][nt].y}, ex, off, 0, AUX_SC1);
+            // all four workgroups of the pair on ONE XCD (checked, below): the image stays in that XCD's L2 — plain stores, drained the
+            // same way; the partners' sc1 loads are served by the same L2.  Otherwise write-through, as the visibility rules demand.
+            if (same_xcd) __builtin_amdgcn_raw_buffer_store_b64(u32x2{o[i][nt].x, o[i][nt].y}, ex, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b64(u32x2{o[i][nt].x, o[i][nt].y}, ex, off, 0, AUX_SC1);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its stores
@@ -210,6 +215,12 @@ __device__ __forceinline__ bool sc_wave(uint8_t* lds, int pair, int cg, int bloc
                                         uint32_t tower_bytes, const float* __restrict__ fold, uint8_t* __restrict__ ex_base, uint32_t ex_bytes_total,
                                         unsigned* counter, unsigned* err)
 {
+    // which XCD this workgroup runs on: every workgroup of the pair adds 1 to the 3-bit field of its XCC in the pair's word before its
+    // stem stores are drained and counted; behind the stem's hand-off the word says whether all four share one XCD (speed only: the
+    // layers' images then stay in that L2 — profiles/r03_small_batch_tower.txt: 5 % of a launch)
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (3 << 11)) & 7u;
+    unsigned* xccw = counter + MAX_PAIRS;
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(xccw, 1u << (3u * xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint8_t* bufX = lds;
     const uint8_t* bufF = lds + FEAT_OFF;
     const uint8_t* taprow = lds + TAPROW_OFF;
@@ -264,8 +275,10 @@ __device__ __forceinline__ bool sc_wave(uint8_t* lds, int pair, int cg, int bloc
         }
     }
     const __amdgpu_buffer_rsrc_t ex = __builtin_amdgcn_make_buffer_rsrc(ex_base, (short)0, (int)ex_bytes_total, 0x00020000);
-    publish<MH>(bufX, o, 1, pair, ct0, c, g, tid, ex, counter);
+    publish<MH>(bufX, o, 1, pair, ct0, c, g, tid, ex, counter, false);
     gather(bufX, 1, pair, cg, tid, ex, counter, err);
+    // (thread 0's add above was drained with the stem's stores — vmcnt(0) in publish — before this workgroup was counted in)
+    const bool same_xcd = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(xccw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == (int)((unsigned)CGN << (3u * xcc));
 
     // ---- residual tower
     const uint8_t* tr_c = taprow + c;
@@ -314,7 +327,7 @@ __device__ __forceinline__ bool sc_wave(uint8_t* lds, int pair, int cg, int bloc
 #pragma unroll
                 for (int nt = 0; nt < NTW; nt++) o[i][nt] = bn_relu_pack<false, F16>(acc[i][nt], sc[nt], sh[nt], uint2{0, 0});
         }
-        publish<MH>(bufX, o, L + 2, pair, ct0, c, g, tid, ex, counter);
+        publish<MH>(bufX, o, L + 2, pair, ct0, c, g, tid, ex, counter, same_xcd);
         if (L == layers - 1) {
             if (cg != 0) return false;   // after the last layer only channel group 0 goes on (the heads)
         } else {
@@ -470,7 +483,6 @@ __global__ __launch_bounds__(THREADS) void k_tower_sc(const uint8_t* __restrict_
     }
 }
 
-constexpr int MAX_PAIRS = 64;
 }  // namespace
 
 namespace azr {
@@ -481,8 +493,8 @@ int tower_sc_init(azr_engine* h)
     const size_t ex_bytes = (size_t)2 * MAX_PAIRS * EX_PAIR_BYTES;   // [pair][parity of the epoch][96 rows][256] bf16
     HIPCHK(h, hipMalloc((void**)&x->sc_ex, ex_bytes));
     HIPCHK(h, hipMemsetAsync(x->sc_ex, 0, ex_bytes, h->stream));
-    HIPCHK(h, hipMalloc((void**)&x->sc_counters, (MAX_PAIRS + 4) * sizeof(unsigned)));   // [MAX_PAIRS] arrival counters | error word
-    HIPCHK(h, hipMemsetAsync(x->sc_counters, 0, (MAX_PAIRS + 4) * sizeof(unsigned), h->stream));
+    HIPCHK(h, hipMalloc((void**)&x->sc_counters, (2 * MAX_PAIRS + 4) * sizeof(unsigned)));   // [MAX_PAIRS] arrival counters | [MAX_PAIRS] XCC words | error word
+    HIPCHK(h, hipMemsetAsync(x->sc_counters, 0, (2 * MAX_PAIRS + 4) * sizeof(unsigned), h->stream));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_sc<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_sc<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     return AZR_OK;
@@ -508,13 +520,13 @@ int tower_sc_launch(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, 
     const uint32_t tower_bytes = (uint32_t)(((size_t)2 * B * TOWER_LAYER_HALFS + MAX_RING * KSTRIDE * 8) * 2);
     const uint32_t ex_bytes = (uint32_t)((size_t)2 * MAX_PAIRS * EX_PAIR_BYTES);
     // the arrival counters count within ONE launch: zeroed ahead of it, in stream order
-    HIPCHK(h, hipMemsetAsync(x->sc_counters, 0, MAX_PAIRS * sizeof(unsigned), st));
+    HIPCHK(h, hipMemsetAsync(x->sc_counters, 0, 2 * MAX_PAIRS * sizeof(unsigned), st));
     if (x->f16)
         hipLaunchKernelGGL(k_tower_sc<true>, dim3(wgs), dim3(THREADS), LDS_BYTES, st, d_in88, in_stride, n, pairs, x->stem_wp, x->tower_wp, tower_bytes, (const float*)x->fold16, B,
-                           net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_counters + MAX_PAIRS);
+                           net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_counters + 2 * MAX_PAIRS);
     else
         hipLaunchKernelGGL(k_tower_sc<false>, dim3(wgs), dim3(THREADS), LDS_BYTES, st, d_in88, in_stride, n, pairs, x->stem_wp, x->tower_wp, tower_bytes, net_fold(h), B,
-                           net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_counters + MAX_PAIRS);
+                           net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_counters + 2 * MAX_PAIRS);
     HIPCHK(h, hipGetLastError());
     return AZR_OK;
 }
@@ -525,7 +537,7 @@ int tower_sc_check(azr_engine* h)
     Bf16Net* x = bf16net(h);
     if (!x || !x->sc_counters) return AZR_OK;
     unsigned e = 0;
-    HIPCHK(h, hipMemcpy(&e, x->sc_counters + MAX_PAIRS, sizeof e, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(&e, x->sc_counters + 2 * MAX_PAIRS, sizeof e, hipMemcpyDeviceToHost));
     if (e) { h->err = "k_tower_sc: a workgroup waited for its pair longer than the spin limit (the launch was not fully resident?)"; return AZR_E_HIP; }
     return AZR_OK;
 }
