@@ -111,7 +111,7 @@ struct Bf16Net {
     uint16_t* tower_wp = nullptr;
     unsigned long long* diag = nullptr;  // set only by azr_debug_tower_clock
     int sb_mode = 1;   // use of the single-image tiles: 0 never, 1 plan, 2 / 3 / 4 force 4 / 2 / 3 boards (AZR_TOWER_SB, read once at creation)
-    int sc_mode = 1;   // launches of <= 256 boards on the split-channel tower (azr_tower_sc.hip); 0 = one board per workgroup (AZR_TOWER_SC, read once at creation)
+    int sc_mode = 1;   // launches of <= 128 boards on the split-channel tower (azr_tower_sc.hip); 0 = one board per workgroup (AZR_TOWER_SC, read once at creation)
     uint16_t* sc_ex = nullptr;        // split-channel tower: the exchange images [2 parities][128 pairs][96 rows][256] bf16
     unsigned* sc_counters = nullptr;  // ... the pairs' arrival counters [128] and the error word
 };

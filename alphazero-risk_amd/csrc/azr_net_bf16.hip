@@ -573,7 +573,7 @@ int net_bf16_alloc(azr_engine* h)
     // workgroup) for every launch — the independently written implementation the single-image tiles are compared with bit for bit;
     // 1 (default): plan; 2 / 3 / 4: force the 4- / 2- / 3-board single-image tile
     x->sb_mode = getenv("AZR_TOWER_SB") ? atoi(getenv("AZR_TOWER_SB")) : 1;
-    // AZR_TOWER_SC=0: launches of <= 256 boards on k_tower_bf16<1> instead of the split-channel tower (A/B measurements)
+    // AZR_TOWER_SC=0: launches of <= 128 boards on k_tower_bf16<1> (NET_F16: 2-board tiles) instead of the split-channel tower (A/B measurements, tests)
     x->sc_mode = getenv("AZR_TOWER_SC") ? atoi(getenv("AZR_TOWER_SC")) : 1;
     int rc = tower_sc_init(h);
     if (rc) return rc;

@@ -68,7 +68,7 @@ def test_checkpoint_roundtrip(tmp_path):
 def test_bf16_mfma_tower_matches_fp32_oracle(orc, n, blocks):
     """bf16 MFMA path (bf16 weights and inter-layer activations, fp32 accumulate/epilogue) vs the fp32 oracle.
     Stated tolerance: max |dpi| <= 2e-2, max |dv| <= 2e-2; typical error is ~1e-3.
-    n selects the tile: up to 256 boards one per workgroup (k_tower_bf16<1>), above that the single-image tiles of 2, 3 or 4
+    n selects the tile: up to 128 boards the split-channel tower (k_tower_sc), 129 .. 256 one per workgroup (k_tower_bf16<1>), above that the single-image tiles of 2, 3 or 4
     boards (k_tower_sb<NB>, the planner's choice)."""
     P = pkg()
     base = sample_inputs(64)
