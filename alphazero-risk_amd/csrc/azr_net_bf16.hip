@@ -138,7 +138,7 @@ template <> struct BnConst<false> { typedef float type; };           // 1 channe
 // one tap = 8 k-steps against ring slots SB .. SB+7.  `wb` is the wave-UNIFORM byte pointer to the current
 // k-step's 16-KiB fragment block (advanced with scalar adds); `loff` is this lane's byte offset inside a block.
 // SK / SKN: skip_mask of this tap / of the tap whose first fragments are prefetched at the end (all ones = none)
-template <int MT, int NT, int RT, int SB, uint32_t SK, uint32_t SKN>
+template <int MT, int NT, int RT, int SB, uint32_t SK, uint32_t SKN, bool F16>
 __device__ __forceinline__ void conv_tap(const uint8_t* IN, int tap, const char* __restrict__& wb, uint32_t loff,
                                          s16x8 (&bq)[RT * 8][NT], f32x4 (&acc)[MT][NT], s16x8 (&a)[2][MT], int (&aoff)[MT],
                                          const int (&rinfo)[MT], int g16, const uint8_t* __restrict__ rowof, int zero_row)
@@ -175,11 +175,9 @@ __device__ __forceinline__ void conv_tap(const uint8_t* IN, int tap, const char*
                 } else if constexpr (Swap<MT>::value)
                     // weights as the MFMA "A" operand, activations as "B": D[channel][cell], so a lane ends up with 4
                     // CONSECUTIVE CHANNELS of one board cell (row = 4*(lane>>4)+j, col = lane&15) -> 8-byte LDS stores
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bq[SB + ks][nt]),
-                                                                          __builtin_bit_cast(bf16x8, a[cur][mt]), acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = El<F16>::mfma(bq[SB + ks][nt], a[cur][mt], acc[mt][nt]);
                 else
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[cur][mt]),
-                                                                          __builtin_bit_cast(bf16x8, bq[SB + ks][nt]), acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = El<F16>::mfma(a[cur][mt], bq[SB + ks][nt], acc[mt][nt]);
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
             bq[SB + ks][nt] = *reinterpret_cast<const s16x8*>(wb + RT * 8 * KBYTES + loff + nt * 1024);
@@ -198,7 +196,7 @@ __device__ __forceinline__ void conv_tap(const uint8_t* IN, int tap, const char*
 // next layer's weight latency.  A fragments are double-buffered one k-step ahead so their LDS latency hides under
 // the current MFMAs; scheduling regions (sched_barrier) keep that order.
 // PAR = parity of the layer's first tap in the global tap sequence (9 taps per layer: it alternates per layer).
-template <int MT, int NT, int RT, int PAR>
+template <int MT, int NT, int RT, int PAR, bool F16>
 __device__ __forceinline__ void conv_tower_layer(const uint8_t* IN, const char* __restrict__& wb, uint32_t loff,
                                                  s16x8 (&bq)[RT * 8][NT], f32x4 (&acc)[MT][NT], const int (&rinfo)[MT], int g16,
                                                  const uint8_t* __restrict__ rowof, int zero_row, const float* __restrict__ fs, typename BnConst<Swap<MT>::value>::type (&sc)[NT],
@@ -234,22 +232,22 @@ __device__ __forceinline__ void conv_tower_layer(const uint8_t* IN, const char* 
     };
     if constexpr (RT == 1) {
         load_bn();  // (register allocation at the 256-VGPR limit of the 3-board tile is best with the early load)
-#define AZR_TAP(T) conv_tap<MT, NT, 1, 0, skip_mask<NBX>(T), skip_mask<NBX>(T + 1)>(IN, T, wb, loff, bq, acc, a, aoff, rinfo, g16, rowof, zero_row)
+#define AZR_TAP(T) conv_tap<MT, NT, 1, 0, skip_mask<NBX>(T), skip_mask<NBX>(T + 1), F16>(IN, T, wb, loff, bq, acc, a, aoff, rinfo, g16, rowof, zero_row)
         AZR_TAP(0); AZR_TAP(1); AZR_TAP(2); AZR_TAP(3); AZR_TAP(4); AZR_TAP(5); AZR_TAP(6); AZR_TAP(7); AZR_TAP(8);
 #undef AZR_TAP
     } else {
         constexpr int S0 = PAR ? 8 : 0, S1 = PAR ? 0 : 8;
         for (int tap = 0; tap < 8; tap += 2) {
-            conv_tap<MT, NT, 2, S0, 0u, 0u>(IN, tap, wb, loff, bq, acc, a, aoff, rinfo, g16, rowof, zero_row);
-            conv_tap<MT, NT, 2, S1, 0u, 0u>(IN, tap + 1, wb, loff, bq, acc, a, aoff, rinfo, g16, rowof, zero_row);
+            conv_tap<MT, NT, 2, S0, 0u, 0u, F16>(IN, tap, wb, loff, bq, acc, a, aoff, rinfo, g16, rowof, zero_row);
+            conv_tap<MT, NT, 2, S1, 0u, 0u, F16>(IN, tap + 1, wb, loff, bq, acc, a, aoff, rinfo, g16, rowof, zero_row);
         }
         load_bn();
-        conv_tap<MT, NT, 2, S0, 0u, 0u>(IN, 8, wb, loff, bq, acc, a, aoff, rinfo, g16, rowof, zero_row);
+        conv_tap<MT, NT, 2, S0, 0u, 0u, F16>(IN, 8, wb, loff, bq, acc, a, aoff, rinfo, g16, rowof, zero_row);
     }
 }
 
 // the whole network for the NB boards [board0, board0 + NB) of one workgroup
-template <int NB, int NT>
+template <int NB, int NT, bool F16>
 __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int board0, const uint8_t* __restrict__ in88, int in_stride,
                                            int n, const uint16_t* __restrict__ stem_wp, const uint16_t* __restrict__ tower_wp,
                                            const float* __restrict__ fold, int blocks, const float* __restrict__ hp,
@@ -302,7 +300,7 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
         float v = 0.0f;
         const int ci = r < ZR ? rowcell[r] : 0xffff;
         if (ci != 0xffff) v = plane_value(in_l + (ci >> 8) * 96, (ci & 15) * 6 + ((ci >> 4) & 15), c);
-        reinterpret_cast<uint16_t*>(bufT)[i] = bf_rne(v);
+        reinterpret_cast<uint16_t*>(bufT)[i] = El<F16>::rne(v);
     }
     __syncthreads();
 
@@ -343,9 +341,9 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++)
                     if constexpr (Swap<MT>::value)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[nt]), __builtin_bit_cast(bf16x8, av), acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = El<F16>::mfma(b[nt], av, acc[mt][nt]);
                     else
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, b[nt]), acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = El<F16>::mfma(av, b[nt], acc[mt][nt]);
             }
         }
         if constexpr (Swap<MT>::value) {
@@ -363,7 +361,7 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const float v = fmaf(acc[mt][nt][j], sc, sh);
-                        o4[j] = bf_rne(v > 0.0f ? v : 0.0f);
+                        o4[j] = El<F16>::rne(v > 0.0f ? v : 0.0f);
                     }
                     *reinterpret_cast<uint2*>(bufX + r * ROWB + c0 * 2) = uint2{(uint32_t)o4[0] | ((uint32_t)o4[1] << 16), (uint32_t)o4[2] | ((uint32_t)o4[3] << 16)};
                 }
@@ -383,7 +381,7 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
 #pragma unroll
                         for (int nt = 0; nt < NT; nt++) {
                             const float v = fmaf(acc[mt][nt][j], sc, sh);
-                            reinterpret_cast<uint16_t*>(bufX + r * ROWB)[wave * WCOLS + nt * 16 + m] = bf_rne(v > 0.0f ? v : 0.0f);
+                            reinterpret_cast<uint16_t*>(bufX + r * ROWB)[wave * WCOLS + nt * 16 + m] = El<F16>::rne(v > 0.0f ? v : 0.0f);
                         }
                     }
                 }
@@ -406,8 +404,8 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
                         for (int nt = 0; nt < NT; nt++) {
                             uint16_t* o = reinterpret_cast<uint16_t*>(OUT + r * ROWB) + wave * WCOLS + nt * 16 + m;
                             float v = fmaf(acc[mt][nt][j], bn_x(sc[nt]), bn_x(sh[nt]));
-                            if (second) v += bf2f(*o);  // shortcut: OUT still holds the block's input at this element
-                            *o = bf_rne(v > 0.0f ? v : 0.0f);
+                            if (second) v += El<F16>::tof(*o);  // shortcut: OUT still holds the block's input at this element
+                            *o = El<F16>::rne(v > 0.0f ? v : 0.0f);
                         }
                     }
                 }
@@ -425,11 +423,11 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
                     float v2 = fmaf(acc[mt][nt][2], s4.z, h4.z), v3 = fmaf(acc[mt][nt][3], s4.w, h4.w);
                     if (second) {  // shortcut: OUT still holds the block's input at these 4 channels of this cell
                         const uint2 x = *o;
-                        v0 += bf2f((uint16_t)(x.x & 0xffffu)); v1 += bf2f((uint16_t)(x.x >> 16));
-                        v2 += bf2f((uint16_t)(x.y & 0xffffu)); v3 += bf2f((uint16_t)(x.y >> 16));
+                        v0 += El<F16>::tof((uint16_t)(x.x & 0xffffu)); v1 += El<F16>::tof((uint16_t)(x.x >> 16));
+                        v2 += El<F16>::tof((uint16_t)(x.y & 0xffffu)); v3 += El<F16>::tof((uint16_t)(x.y >> 16));
                     }
-                    const uint32_t lo = (uint32_t)bf_rne(v0 > 0.0f ? v0 : 0.0f) | ((uint32_t)bf_rne(v1 > 0.0f ? v1 : 0.0f) << 16);
-                    const uint32_t hi = (uint32_t)bf_rne(v2 > 0.0f ? v2 : 0.0f) | ((uint32_t)bf_rne(v3 > 0.0f ? v3 : 0.0f) << 16);
+                    const uint32_t lo = (uint32_t)El<F16>::rne(v0 > 0.0f ? v0 : 0.0f) | ((uint32_t)El<F16>::rne(v1 > 0.0f ? v1 : 0.0f) << 16);
+                    const uint32_t hi = (uint32_t)El<F16>::rne(v2 > 0.0f ? v2 : 0.0f) | ((uint32_t)El<F16>::rne(v3 > 0.0f ? v3 : 0.0f) << 16);
                     *o = uint2{lo, hi};
                 }
             }
@@ -438,10 +436,10 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
     for (int blk = 0; blk < blocks; blk++) {
         bn_t sc[NT], sh[NT];
         const float* fs = fold + 14 + (size_t)(2 * blk) * 2 * NF + wave * WCOLS + (Swap<MT>::value ? g * 4 : m);
-        conv_tower_layer<MT, NT, RT, 0>(bufX, wb, loff, bq, acc, rinfo, g16, rowof, ZR, fs, sc, sh);
+        conv_tower_layer<MT, NT, RT, 0, F16>(bufX, wb, loff, bq, acc, rinfo, g16, rowof, ZR, fs, sc, sh);
         epilogue(false, bufT, sc, sh);
         __syncthreads();
-        conv_tower_layer<MT, NT, RT, 1>(bufT, wb, loff, bq, acc, rinfo, g16, rowof, ZR, fs + 2 * NF, sc, sh);
+        conv_tower_layer<MT, NT, RT, 1, F16>(bufT, wb, loff, bq, acc, rinfo, g16, rowof, ZR, fs + 2 * NF, sc, sh);
         epilogue(true, bufX, sc, sh);
         __syncthreads();
     }
@@ -477,10 +475,10 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
             for (int q = 0; q < NF / 8; q++) {
                 const s16x8 xx = x8[q];
                 const float4 wa = w4[2 * q], wb = w4[2 * q + 1];
-                sacc = fmaf(bf2f((uint16_t)xx[0]), wa.x, sacc); sacc = fmaf(bf2f((uint16_t)xx[1]), wa.y, sacc);
-                sacc = fmaf(bf2f((uint16_t)xx[2]), wa.z, sacc); sacc = fmaf(bf2f((uint16_t)xx[3]), wa.w, sacc);
-                sacc = fmaf(bf2f((uint16_t)xx[4]), wb.x, sacc); sacc = fmaf(bf2f((uint16_t)xx[5]), wb.y, sacc);
-                sacc = fmaf(bf2f((uint16_t)xx[6]), wb.z, sacc); sacc = fmaf(bf2f((uint16_t)xx[7]), wb.w, sacc);
+                sacc = fmaf(El<F16>::tof((uint16_t)xx[0]), wa.x, sacc); sacc = fmaf(El<F16>::tof((uint16_t)xx[1]), wa.y, sacc);
+                sacc = fmaf(El<F16>::tof((uint16_t)xx[2]), wa.z, sacc); sacc = fmaf(El<F16>::tof((uint16_t)xx[3]), wa.w, sacc);
+                sacc = fmaf(El<F16>::tof((uint16_t)xx[4]), wb.x, sacc); sacc = fmaf(El<F16>::tof((uint16_t)xx[5]), wb.y, sacc);
+                sacc = fmaf(El<F16>::tof((uint16_t)xx[6]), wb.z, sacc); sacc = fmaf(El<F16>::tof((uint16_t)xx[7]), wb.w, sacc);
             }
             const float* bnp = c < 2 ? bnpi : bnv;
             const int nc = c < 2 ? 2 : 1, kk = c < 2 ? c : 0;
@@ -531,7 +529,7 @@ __device__ __forceinline__ void tower_body(uint8_t* __restrict__ lds, const int 
 // Workgroups [0, n_full) carry NB boards, the rest NB - 1: a batch that is not a whole number of 256-workgroup waves of
 // NB boards is split into whole waves of mixed size instead (2048 boards = 512 x 3 + 256 x 2: each CU slot runs 3 + 3 + 2
 // boards rather than a 2.67-wave tail).  NB - 1 runs the NB - 1 instantiation of the same body inside this kernel's LDS.
-template <int NB, int NT>
+template <int NB, int NT, bool F16>
 __global__ __launch_bounds__(1024 / NT, NT == 2 ? 2 : 1) void k_tower_bf16(const uint8_t* __restrict__ in88, int in_stride, int n,
                                                                            const uint16_t* __restrict__ stem_wp,
                                                                            const uint16_t* __restrict__ tower_wp,
@@ -545,12 +543,12 @@ __global__ __launch_bounds__(1024 / NT, NT == 2 ? 2 : 1) void k_tower_bf16(const
     const int bid = blockIdx.x;
     if constexpr (NB >= 2) {
         if (bid >= n_full) {
-            tower_body<NB - 1, NT>(lds, n_full * NB + (bid - n_full) * (NB - 1), in88, in_stride, n, stem_wp, tower_wp, fold, blocks, hp,
+            tower_body<NB - 1, NT, F16>(lds, n_full * NB + (bid - n_full) * (NB - 1), in88, in_stride, n, stem_wp, tower_wp, fold, blocks, hp,
                                    pi_out, v_out, diag, slot_map);
             return;
         }
     }
-    tower_body<NB, NT>(lds, bid * NB, in88, in_stride, n, stem_wp, tower_wp, fold, blocks, hp, pi_out, v_out, diag, slot_map);
+    tower_body<NB, NT, F16>(lds, bid * NB, in88, in_stride, n, stem_wp, tower_wp, fold, blocks, hp, pi_out, v_out, diag, slot_map);
 }
 
 Bf16Net* bn(azr_engine* h) { return bf16net(h); }
@@ -568,12 +566,13 @@ int net_bf16_alloc(azr_engine* h)
     HIPCHK(h, hipMalloc((void**)&x->stem_wp, STEM_HALFS * 2));
     HIPCHK(h, hipMalloc((void**)&x->tower_wp, ((size_t)2 * B * TOWER_LAYER_HALFS + MAX_RING * KSTRIDE * 8) * 2));  // + ring run-off
     HIPCHK(h, hipMemsetAsync(x->tower_wp, 0, ((size_t)2 * B * TOWER_LAYER_HALFS + MAX_RING * KSTRIDE * 8) * 2, h->stream));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<1>::LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<1, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<1>::LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<1, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<1>::LDS_BYTES));
     // test / measurement switch, read ONCE, here (never in the launch path): AZR_TOWER_SB = 0: the two-image kernel (one board per
     // workgroup) for every launch — the independently written implementation the single-image tiles are compared with bit for bit;
     // 1 (default): plan; 2 / 3 / 4: force the 4- / 2- / 3-board single-image tile
     x->sb_mode = getenv("AZR_TOWER_SB") ? atoi(getenv("AZR_TOWER_SB")) : 1;
-    // AZR_TOWER_SC=0: launches of <= 128 boards on k_tower_bf16<1> (NET_F16: 2-board tiles) instead of the split-channel tower (A/B measurements, tests)
+    // AZR_TOWER_SC=0: launches of <= 128 boards on k_tower_bf16<1> instead of the split-channel tower (A/B measurements, tests)
     x->sc_mode = getenv("AZR_TOWER_SC") ? atoi(getenv("AZR_TOWER_SC")) : 1;
     int rc = tower_sc_init(h);
     if (rc) return rc;
@@ -679,10 +678,10 @@ int net_bf16_upload(azr_engine* h, const float* fold_host)
 // Single-image tiles (azr_tower_sb.hip) for 2, 3 or 4 boards per workgroup: boards per workgroup for a launch of n boards,
 // or 0 = the two-image kernels (1..3 boards).  AZR_TOWER_SB: 0 = never, 1 = plan (default), 2 / 3 / 4 = force the 4- / 2- /
 // 3-board tile for every launch (tests, measurements).
-static int plan_sb(int sb_mode, int n, bool any_n = false)   // any_n: the tile plan for launches of <= 256 boards too (NET_F16 has no one-board kernel)
+static int plan_sb(int sb_mode, int n)
 {
     int snb = sb_mode == 2 ? 4 : sb_mode == 3 ? 2 : sb_mode == 4 ? 3 : 0;
-    if (snb == 0 && (any_n || (sb_mode == 1 && n > 256))) {
+    if (sb_mode == 1 && n > 256) {
         // Relative time of one 256-workgroup round of 2 / 3 / 4 boards per workgroup.  One workgroup per CU is resident, so a launch
         // of w workgroups takes ceil(w / 256) rounds, and only the RATIOS of the round times enter the choice: the three tiles are
         // the same MFMA-bound code, so a box that clocks lower stretches all three alike.  The ratios are those of the tiles'
@@ -698,7 +697,7 @@ static int plan_sb(int sb_mode, int n, bool any_n = false)   // any_n: the tile 
             if (snb == 0 || t < best) { snb = c; best = t; }
         }
     }
-    return (n >= snb || any_n) ? snb : 0;
+    return n >= snb ? snb : 0;
 }
 
 int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st)
@@ -707,16 +706,6 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
     const float* fold = net_fold(h);
     const int B = h->net.blocks;
     if (h->pe_tower0) hipEventRecord(h->pe_tower0, st);
-    if (x->f16) {   // NET_F16: the split-channel tower up to 128 boards, the single-image tiles above (2 boards per workgroup up to 512)
-        int rc;
-        if (x->sb_mode <= 1 && x->sc_mode != 0 && n <= 128) rc = tower_sc_launch(h, d_in88, in_stride, n, d_pi, d_v, d_map, st);
-        else {
-            const int snb = plan_sb(x->sb_mode, n, true);
-            rc = tower_sb_launch(h, snb, (n + snb - 1) / snb, d_in88, in_stride, n, d_pi, d_v, d_map, st);
-        }
-        if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
-        return rc;
-    }
     if (const int snb = plan_sb(x->sb_mode, n)) {   // more than 256 boards: 2, 3 or 4 per workgroup in one LDS image (azr_tower_sb.hip)
         int rc = tower_sb_launch(h, snb, (n + snb - 1) / snb, d_in88, in_stride, n, d_pi, d_v, d_map, st);
         if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
@@ -728,8 +717,12 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
         return rc;
     }
     // AZR_TOWER_SB=0 / AZR_TOWER_SC=0: one board per workgroup for the whole net, two ping-pong images, 8 waves x 32 channels
-    hipLaunchKernelGGL((k_tower_bf16<1, 2>), dim3(n), dim3(512), Geo<1>::LDS_BYTES, st, d_in88, in_stride, n, x->stem_wp, x->tower_wp, fold, B,
-                       net_head_params(h), d_pi, d_v, x->diag, n, d_map);
+    if (x->f16)
+        hipLaunchKernelGGL((k_tower_bf16<1, 2, true>), dim3(n), dim3(512), Geo<1>::LDS_BYTES, st, d_in88, in_stride, n, x->stem_wp, x->tower_wp,
+                           (const float*)x->fold16, B, net_head_params(h), d_pi, d_v, x->diag, n, d_map);
+    else
+        hipLaunchKernelGGL((k_tower_bf16<1, 2, false>), dim3(n), dim3(512), Geo<1>::LDS_BYTES, st, d_in88, in_stride, n, x->stem_wp, x->tower_wp, fold, B,
+                           net_head_params(h), d_pi, d_v, x->diag, n, d_map);
     if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
     HIPCHK(h, hipGetLastError());
     return AZR_OK;
@@ -764,11 +757,9 @@ static int tower_diag_run(azr_engine* h, int n, int warm, std::vector<unsigned l
 extern "C" int azr_debug_tower_plan(azr_engine* h, int n, int* boards_per_wg, int* wgs)
 {
     if (!h || !h->net.bf16ctx || n < 1) return AZR_E_STATE;
-    const bool f16 = bn(h)->f16;
-    const bool sc = (f16 ? bn(h)->sb_mode <= 1 : bn(h)->sb_mode != 0) && bn(h)->sc_mode != 0 && n <= 128;
-    const int snb = (f16 && sc) ? 0 : plan_sb(bn(h)->sb_mode, n, f16);
+    const int snb = plan_sb(bn(h)->sb_mode, n);
     if (snb) { *boards_per_wg = snb; *wgs = (n + snb - 1) / snb; return AZR_OK; }
-    if (sc) {   // split-channel tower: 4 workgroups of 64 channels per board pair
+    if (bn(h)->sb_mode != 0 && bn(h)->sc_mode != 0 && n <= 128) {   // split-channel tower: 4 workgroups of 64 channels per board pair
         *wgs = ((n + 1) / 2) * 4;
         *boards_per_wg = 2;
         return AZR_OK;

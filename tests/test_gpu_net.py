@@ -223,11 +223,12 @@ def test_tile_shapes_agree_bit_for_bit(monkeypatch, blocks):
         assert (out["0"][1].view(np.uint32) == out[mode][1].view(np.uint32)).all(), mode
 
 
-@pytest.mark.parametrize("n,blocks", [(48, 2), (130, 2), (300, 2), (600, 1), (1100, 1), (16, 20)])
+@pytest.mark.parametrize("n,blocks", [(48, 2), (130, 2), (200, 2), (300, 2), (600, 1), (1100, 1), (16, 20)])
 def test_f16_tower_matches_fp32_oracle(orc, n, blocks):
     """NET_F16: the bf16 tower's kernels on fp16 operands (El<true> in csrc/azr_bf16_common.hpp: same MFMA rate, 11 significand bits;
     conv weights packed as 2^k w per layer with 2^-k in the folded BN scale).  Stated tolerance: max |d pi|, |d v| <= 3e-3 of the fp32
-    oracle (bf16: 2e-2).  n selects the tile: up to 128 boards the split-channel tower, above that 2, 3 or 4 boards per workgroup."""
+    oracle (bf16: 2e-2).  n selects the tile as for bf16: up to 128 boards the split-channel tower, 129 .. 256 one board per workgroup, above
+    that 2, 3 or 4 boards per workgroup."""
     P = pkg()
     base = sample_inputs(64)
     x = np.concatenate([base] * ((n + 63) // 64))[:n].copy()
@@ -250,15 +251,16 @@ def test_f16_tower_matches_fp32_oracle(orc, n, blocks):
 
 
 def test_f16_tile_shapes_agree_bit_for_bit(monkeypatch):
-    """NET_F16 at the bench's depth: the plan (split-channel tower up to 128 boards, 2 / 3 / 4 boards per workgroup above) and the
-    forced 4- / 2- / 3-board tiles compute the same bits, full and ragged batches; weights outside the fp16 range are refused"""
+    """NET_F16 at the bench's depth: the plan (split-channel tower up to 128 boards, one board per workgroup up to 256, 2 / 3 / 4 boards
+    per workgroup above), the forced 4- / 2- / 3-board tiles and the independently written two-image kernel with one board per
+    workgroup (AZR_TOWER_SB=0) compute the same bits, full and ragged batches; weights outside the fp16 range are refused"""
     P = pkg()
     n, blocks = 1024, 20
     g = np.unique(np.load(os.path.join(T.GOLDEN, "encode.npz"))["in88"], axis=0)
     x = g[np.linspace(0, len(g) - 1, n).astype(int)].copy()
     flat = T.make_net_flat(blocks, seed=3, perturb_bn=True)
     out = {}
-    for mode in ("1", "2", "3", "4"):
+    for mode in ("0", "1", "2", "3", "4"):
         monkeypatch.setenv("AZR_TOWER_SB", mode)
         eng = P.Engine(n, blocks=blocks, sims=1, dtype=P.NET_F16, node_capacity=64)
         eng.set_weights(flat)
@@ -272,9 +274,9 @@ def test_f16_tile_shapes_agree_bit_for_bit(monkeypatch):
             with pytest.raises(Exception):
                 eng.set_weights(bad)
         eng.close()
-    for mode in ("2", "3", "4"):
-        assert (out["1"][0].view(np.uint32) == out[mode][0].view(np.uint32)).all(), mode
-        assert (out["1"][1].view(np.uint32) == out[mode][1].view(np.uint32)).all(), mode
+    for mode in ("1", "2", "3", "4"):
+        assert (out["0"][0].view(np.uint32) == out[mode][0].view(np.uint32)).all(), mode
+        assert (out["0"][1].view(np.uint32) == out[mode][1].view(np.uint32)).all(), mode
 
 
 def test_split_channel_tower_under_contention(monkeypatch):
