@@ -158,3 +158,34 @@ def test_seed_streams_are_per_game_and_restart_advances():
             break
     assert a.counters()["games_finished"] >= G
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
+def test_quota_selfplay_is_a_function_of_the_seeds_alone(dtype_name):
+    """exactly N games in quota mode (azr_selfplay_start_games: game k plays seed base + k) on engines of 96, 40 and 7 slots: the
+    launches differ in every way — leaves per pass from 192 down to 1, so the split-channel tower (<= 128 boards), the one-board
+    kernel (129 .. 256) and the emptying tail all run, games finish in another order — but a game is a function of its seed and the
+    tower's tiles agree bit for bit, so the multiset of finished records must be the same, byte for byte"""
+    P = pkg()
+    dt = {"bf16": P.NET_BF16, "f16": P.NET_F16}[dtype_name]
+    N, S, blocks = 120, 8, 2
+    out = []
+    for G in (96, 40, 7):
+        eng = P.Engine(G, blocks=blocks, sims=S, dtype=dt, threads=2, max_game_rounds=40)
+        eng.init_random(5)
+        eng.selfplay_start_games(4242, N)
+        recs = []
+        for _ in range(4000):
+            eng.selfplay_run(64)
+            c = eng.counters()
+            recs.append(eng.drain())
+            if c["games_finished"] >= N:
+                break
+        c = eng.counters()
+        assert c["games_finished"] == N and c["errors"] == 0 and c["records_dropped"] == 0, c
+        r = np.concatenate(recs)
+        assert len(r) == c["samples"]
+        out.append(r[np.lexsort(r.T[::-1])])   # records sorted bytewise
+        eng.close()
+    assert out[0].shape == out[1].shape == out[2].shape and len(out[0]) > 100
+    assert (out[0] == out[1]).all() and (out[0] == out[2]).all()
