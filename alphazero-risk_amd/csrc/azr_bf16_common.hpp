@@ -113,7 +113,8 @@ struct Bf16Net {
     int sb_mode = 1;   // use of the single-image tiles: 0 never, 1 plan, 2 / 3 / 4 force 4 / 2 / 3 boards (AZR_TOWER_SB, read once at creation)
     int sc_mode = 1;   // launches of <= 128 boards on the split-channel tower (azr_tower_sc.hip); 0 = one board per workgroup (AZR_TOWER_SC, read once at creation)
     uint16_t* sc_ex = nullptr;        // split-channel tower: the exchange images [2 parities][128 pairs][96 rows][256] bf16
-    unsigned* sc_counters = nullptr;  // ... the pairs' arrival counters [128] and the error word
+    unsigned* sc_counters = nullptr;  // ... the pairs' arrival counters and XCC words
+    unsigned *sc_err_host = nullptr, *sc_err_dev = nullptr;   // ... the error word (mapped host memory) and its device address
 };
 inline Bf16Net* bf16net(azr_engine* h) { return reinterpret_cast<Bf16Net*>(h->net.bf16ctx); }
 const float* net_head_params(azr_engine* h);

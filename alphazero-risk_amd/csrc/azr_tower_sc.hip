@@ -189,7 +189,7 @@ __device__ __forceinline__ void gather(uint8_t* bufX, int epoch, int pair, int c
         unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (++spins > SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }   // (the error word is host memory)
         }
     }
     __syncthreads();
@@ -495,6 +495,10 @@ int tower_sc_init(azr_engine* h)
     HIPCHK(h, hipMemsetAsync(x->sc_ex, 0, ex_bytes, h->stream));
     HIPCHK(h, hipMalloc((void**)&x->sc_counters, (2 * MAX_PAIRS + 4) * sizeof(unsigned)));   // [MAX_PAIRS] arrival counters | [MAX_PAIRS] XCC words | error word
     HIPCHK(h, hipMemsetAsync(x->sc_counters, 0, (2 * MAX_PAIRS + 4) * sizeof(unsigned), h->stream));
+    // the error word lives in mapped host memory: written by a kernel only when a hand-off gives up, read by the host for nothing
+    HIPCHK(h, hipHostMalloc((void**)&x->sc_err_host, 16, hipHostMallocMapped));
+    x->sc_err_host[0] = 0;
+    HIPCHK(h, hipHostGetDevicePointer((void**)&x->sc_err_dev, x->sc_err_host, 0));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_sc<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_sc<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     return AZR_OK;
@@ -506,6 +510,8 @@ void tower_sc_free(azr_engine* h)
     if (!x) return;
     if (x->sc_ex) hipFree(x->sc_ex);
     if (x->sc_counters) hipFree(x->sc_counters);
+    if (x->sc_err_host) hipHostFree(x->sc_err_host);
+    x->sc_err_host = x->sc_err_dev = nullptr;
     x->sc_ex = nullptr;
     x->sc_counters = nullptr;
 }
@@ -523,10 +529,10 @@ int tower_sc_launch(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, 
     HIPCHK(h, hipMemsetAsync(x->sc_counters, 0, 2 * MAX_PAIRS * sizeof(unsigned), st));
     if (x->f16)
         hipLaunchKernelGGL(k_tower_sc<true>, dim3(wgs), dim3(THREADS), LDS_BYTES, st, d_in88, in_stride, n, pairs, x->stem_wp, x->tower_wp, tower_bytes, (const float*)x->fold16, B,
-                           net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_counters + 2 * MAX_PAIRS);
+                           net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_err_dev);
     else
         hipLaunchKernelGGL(k_tower_sc<false>, dim3(wgs), dim3(THREADS), LDS_BYTES, st, d_in88, in_stride, n, pairs, x->stem_wp, x->tower_wp, tower_bytes, net_fold(h), B,
-                           net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_counters + 2 * MAX_PAIRS);
+                           net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_err_dev);
     HIPCHK(h, hipGetLastError());
     return AZR_OK;
 }
@@ -535,9 +541,8 @@ int tower_sc_launch(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, 
 int tower_sc_check(azr_engine* h)
 {
     Bf16Net* x = bf16net(h);
-    if (!x || !x->sc_counters) return AZR_OK;
-    unsigned e = 0;
-    HIPCHK(h, hipMemcpy(&e, x->sc_counters + 2 * MAX_PAIRS, sizeof e, hipMemcpyDeviceToHost));
+    if (!x || !x->sc_err_host) return AZR_OK;
+    const unsigned e = *reinterpret_cast<volatile unsigned*>(x->sc_err_host);   // (the caller has synchronised the stream)
     if (e) { h->err = "k_tower_sc: a workgroup waited for its pair longer than the spin limit (the launch was not fully resident?)"; return AZR_E_HIP; }
     return AZR_OK;
 }
