@@ -37,3 +37,14 @@ def test_no_cpu_fallback():
     P = pkg()
     with pytest.raises(P.AzrError):
         P.Engine(2, blocks=1, sims=1)
+
+
+def test_header_constants_match_the_binding():
+    """the enumerators of include/azr.h that the Python side restates (net arithmetic, player kinds) carry the header's values"""
+    P = pkg()
+    hdr = open(os.path.join(ROOT, "include", "azr.h")).read()
+    vals = {k: int(v) for k, v in re.findall(r"\b(AZR_[A-Z0-9_]+)\s*=\s*(-?\d+)", hdr)}
+    for name in ("F32", "BF16", "F32X", "F16"):
+        assert vals["AZR_NET_" + name] == getattr(P, "NET_" + name), name
+    for name in ("ALPHAZERO", "ALPHAZERO_B"):
+        assert vals["AZR_PLAYER_" + name] == getattr(P, "PLAYER_" + name), name
