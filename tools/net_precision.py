@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where every evaluation of the 20-block net stands against a float64 evaluation of the same graph (PyTorch on the CPU,
 tests/torch_train_ref.py): the oracle's fp32 CPU net (stand-in for the reference's fp32 TensorFlow session), and the engine's
-NET_F32 (fp32 VALU), NET_F32X (fp16-pair MFMA) and NET_BF16 towers, on the 128 distinct boards of tests/test_gpu_net.py.
+NET_F32 (fp32 VALU), NET_F32X (fp16-pair MFMA), NET_F16 and NET_BF16 towers, on the 128 distinct boards of tests/test_gpu_net.py.
     python tools/net_precision.py [blocks]"""
 import ctypes as C
 import importlib
