@@ -35,11 +35,12 @@ class GameResults(C.Structure):
 
 
 PLAYER_ALPHAZERO, PLAYER_SCRIPT, PLAYER_RANDOM, PLAYER_ALPHAZERO_B = 0, 1, 2, 3
+MIRROR_OFF, MIRROR_SEQUENTIAL, MIRROR_CONCURRENT = 0, 1, 2   # azr_arena_start's mirror_games (include/azr.h)
 
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("simulations", "evaluations", "levels", "decisions", "games_finished",
-                                          "samples", "nodes_dropped", "errors", "records_dropped")]
+                                          "samples", "nodes_dropped", "errors", "records_dropped", "tower_fallbacks")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -57,17 +58,20 @@ def dp_unique_id():
     return bytes(b)
 
 
-def lib_path():
-    return os.path.join(CSRC, "libazr_hip.so")
+def lib_path(test_hooks=False):
+    """the product library, or (test_hooks) libazr_hip_test.so: the same sources compiled with -DAZR_TEST_HOOKS — the only build
+    in which the AZR_TOWER_* / AZR_TRAIN_* / AZR_DP_LOOPBACK environment switches exist (csrc/azr_internal.hpp)"""
+    return os.path.join(CSRC, "libazr_hip_test.so" if test_hooks else "libazr_hip.so")
 
 
-def build(jobs=3):
+def build(jobs=4, test_hooks=False):
     """Compile every HIP translation unit for gfx950 (hipcc cross-compiles without a GPU)."""
-    subprocess.check_call(["make", "-s", "-j", str(jobs), "-C", CSRC])
-    return lib_path()
+    subprocess.check_call(["make", "-s", "-j", str(jobs), "-C", CSRC, "test" if test_hooks else "all"])
+    return lib_path(test_hooks)
 
 
 _lib = None
+_libs = {}
 
 EXPORTS = [
     "azr_default_settings", "azr_engine_create", "azr_engine_destroy", "azr_last_error", "azr_engine_games",
@@ -82,11 +86,11 @@ EXPORTS = [
 ]
 
 
-def load_library():
-    """dlopen libazr_hip.so; raises (never falls back) when it has not been built."""
+def load_library(test_hooks=False):
+    """dlopen libazr_hip.so (or the test-hook build); raises (never falls back) when it has not been built."""
     global _lib
-    if _lib is None:
-        p = lib_path()
+    if test_hooks not in _libs:
+        p = lib_path(test_hooks)
         if not os.path.exists(p):
             raise FileNotFoundError(f"{p} missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                     "(the HIP path is the only path; there is no CPU fallback)")
@@ -142,8 +146,10 @@ def load_library():
         L.azr_arena_collect_samples.argtypes = [C.c_void_p, C.c_int]
         L.azr_arena_results.argtypes = [C.c_void_p, C.c_void_p]
         L.azr_arena_log.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        _lib = L
-    return _lib
+        _libs[test_hooks] = L
+        if not test_hooks:
+            _lib = L
+    return _libs[test_hooks]
 
 
 def _p(a):
@@ -154,11 +160,12 @@ class Engine:
     """One handle = one GPU = G concurrent games.  Method names follow the reference seams:
     State / UtilityNN (rules), AlphaZeroNNId (net), AlphaZeroMCTS (search), trainer move loop (self-play)."""
 
-    def __init__(self, games, blocks=20, sims=32, dtype=NET_BF16, device=0, threads=1, **kw):
+    def __init__(self, games, blocks=20, sims=32, dtype=NET_BF16, device=0, threads=1, test_hooks=False, **kw):
         """threads = THREADS_PER_MCTS.  The C default (azr_default_settings) is the reference's 2; this binding defaults
         to 1, the only value at which the reference's search is deterministic and the parity tests are bit-exact
-        against `-t 1` semantics; tests of the T-thread schedule pass it explicitly."""
-        self.L = load_library()
+        against `-t 1` semantics; tests of the T-thread schedule pass it explicitly.  test_hooks: the handle lives in
+        libazr_hip_test.so (tests only: the build whose environment switches select other formulations)."""
+        self.L = load_library(test_hooks)
         s = Settings()
         self.L.azr_default_settings(C.byref(s))
         s.device, s.games, s.blocks, s.mcts_simulations, s.net_dtype = device, games, blocks, sims, dtype
@@ -438,6 +445,8 @@ class Engine:
 
     # ---- arena (GameGroup::playGames)
     def arena_start(self, player1, player2, games, per_slot_cap=0, mirror=True, base_seed=20260001):
+        """mirror: False / True (= MIRROR_SEQUENTIAL, the reference's thread-per-pair form) / MIRROR_CONCURRENT (a pair's two games at
+        the same time on slots 2j, 2j + 1)"""
         self._chk(self.L.azr_arena_start(self.h, player1, player2, games, per_slot_cap, int(mirror), base_seed))
 
     def arena_set_opponent(self, other):

@@ -114,8 +114,12 @@ struct Bf16Net {
     int sc_mode = 1;   // launches of <= 128 boards on the split-channel tower (azr_tower_sc.hip); 0 = one board per workgroup (AZR_TOWER_SC, read once at creation)
     uint16_t* sc_ex = nullptr;        // split-channel tower: the exchange images [2 parities][128 pairs][96 rows][256] bf16
     unsigned* sc_counters = nullptr;  // ... the pairs' arrival counters and XCC words
-    unsigned *sc_err_host = nullptr, *sc_err_dev = nullptr;   // ... the error word (mapped host memory) and its device address
+    unsigned sc_spin_limit = 0;       // ... polls of a hand-off before it gives up (a constant in the product library; a test hook otherwise)
+    int sc_force_wt = 0;              // ... test hook: never the plain-store form of a same-XCD pair
 };
+// words of sc_counters behind the per-pair words: the running launch's give-up word (raised by a hand-off that ran out of polls; the
+// guarded k_tower_bf16<1> launch queued behind every k_tower_sc launch recomputes the batch when it is up) and the count of such launches
+constexpr int SC_W_GIVEUP = 128, SC_W_FALLBACKS = 129, SC_WORDS = 132;
 inline Bf16Net* bf16net(azr_engine* h) { return reinterpret_cast<Bf16Net*>(h->net.bf16ctx); }
 const float* net_head_params(azr_engine* h);
 const float* net_fold(azr_engine* h);
@@ -126,5 +130,5 @@ int tower_sb_launch(azr_engine* h, int nb, int wgs, const uint8_t* d_in88, int i
 int tower_sc_init(azr_engine* h);
 void tower_sc_free(azr_engine* h);
 int tower_sc_launch(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st);
-int tower_sc_check(azr_engine* h);
+int tower_sc_fallbacks(azr_engine* h, unsigned long long* out);
 }  // namespace azr

@@ -621,6 +621,31 @@ __global__ __launch_bounds__(64) void k_arena_step(Dev E)
     if (c.search_tree) { swap_tree_ctl(c, x2); consume_pending(E, g, t2, c, k); swap_tree_ctl(c, x2); }
     else consume_pending(E, g, t, c, k);
     for (;;) {
+        if (c.arena_state == 0 && E.arena_mirror == AZR_MIRROR_CONCURRENT) {
+            // Both games of a mirrored pair at the same time: slot 2j plays half 0 of slot pair j's k-th pair, slot 2j + 1 the
+            // mirrored half (include/azr.h).  Nothing in Game orders the two games (game.cpp:238-254); what they share is the
+            // deal (game.cpp:170-191), and the deal is a function of the pair's seed, so each half deals for itself.
+            const int L = E.G >> 1, lane = g >> 1;
+            const uint32_t half = (uint32_t)g & 1u;
+            const long long pr = (long long)lane + (long long)c.slot_games * L;   // pairs are assigned statically
+            const bool capped = E.arena_slot_cap > 0 && (int)c.slot_games >= E.arena_slot_cap;
+            if (capped || g >= 2 * L || pr >= (long long)(E.arena_total / 2)) { c.arena_state = 2; break; }
+            const uint32_t pseed = E.base_seed + (uint32_t)pr;
+            root.rng = rng_seed(pseed);
+            new_game(root);
+            if (half) {   // Game::newGame's mirrored branch: invertPlayers of the pair's deal, player 1 starts, own dice stream
+                invert_players(root);
+                root.rng = rng_seed(pseed + (1u << 30));
+            }
+            root.cur = half;
+            c.player_start = half;
+            c.seed = pseed;
+            tree_clear(t, c);  // AlphaZeroPlayer::newGame
+            if (two) { swap_tree_ctl(c, x2); tree_clear(t2, c); swap_tree_ctl(c, x2); }
+            c.nsamples = 0;
+            c.sims_done = 0; c.sims_started = 0; c.search_active = 0; c.turn_started = 0; c.pending = 0;
+            c.arena_state = 1;
+        }
         if (c.arena_state == 0) {  // Game::newGame (game.cpp:170-191) for the next Game::playGames(1)
             if (c.pair_phase == 0) {  // Counter::hasNext(2) (game.cpp:14-26)
                 int taken = 0;
@@ -670,7 +695,7 @@ __global__ __launch_bounds__(64) void k_arena_step(Dev E)
             }
             c.slot_games++;
             k.games++;
-            c.player_start ^= 1u;  // Game::incPlayerStart
+            c.player_start ^= 1u;  // Game::incPlayerStart (the concurrent form sets it per game)
             c.pair_phase ^= 1u;
             c.arena_state = 0;
             continue;
@@ -728,6 +753,7 @@ __global__ __launch_bounds__(64) void k_arena_step(Dev E)
             root.err = 0;
             c.player_start = 0; c.pair_phase = 0; c.arena_state = 0;
             c.pending = 0; c.search_active = 0; c.turn_started = 0;
+            if (E.arena_mirror == AZR_MIRROR_CONCURRENT) c.slot_games++;   // statically assigned: go on with the slot's next pair
         }
     }
     if (two && lane_id() == 0) { uint32_t* d2 = E.tctl2 + (size_t)g * 4; d2[0] = x2.search_id; d2[1] = x2.nfree; d2[2] = x2.hiwater; }
@@ -1266,7 +1292,6 @@ extern "C" int azr_mcts_simulate(azr_engine* h)
     std::vector<uint32_t> e(h->d.G);
     HIPCHK(h, hipMemcpy2DAsync(e.data(), 4, &h->d.ctl[0].error, sizeof(Ctl), 4, h->d.G, hipMemcpyDeviceToHost, h->stream));
     SYNC(h);
-    { int rcn = net_check(h); if (rcn) return rcn; }
     for (int g = 0; g < h->d.G; g++)
         if (e[g]) { h->err = "search error in game " + std::to_string(g) + " code " + std::to_string(e[g]); return (int)e[g]; }
     return AZR_OK;
@@ -1399,7 +1424,6 @@ extern "C" int azr_selfplay_run(azr_engine* h, int passes)
         if (prof) { HIPCHK(h, hipEventRecord(h->ev[3 * k + 2], h->stream)); k++; }
     }
     SYNC(h);
-    { int rcn = net_check(h); if (rcn) return rcn; }
     double tn = 0, tt = 0, tw = 0;
     const bool tower_timed = h->cfg.net_dtype == AZR_NET_BF16 || h->cfg.net_dtype == AZR_NET_F32X || h->cfg.net_dtype == AZR_NET_F16;   // one kernel = one net forward, bracketed by events
     for (int i = 0; i < k; i++) {
@@ -1444,6 +1468,18 @@ extern "C" int azr_selfplay_counters(azr_engine* h, azr_counters* out)
     out->decisions = c.decisions; out->games_finished = c.games_finished; out->samples = c.samples;
     out->nodes_dropped = c.nodes_dropped; out->errors = c.errors;
     out->records_dropped = c.ring_dropped;
+    out->tower_fallbacks = 0;
+    {
+        unsigned long long f = 0;
+        int rc = net_fallbacks(h, &f);
+        if (rc) return rc;
+        out->tower_fallbacks = f;
+        if (h->opponent) {   // two-net arena: the opponent's launches ran on its own handle
+            rc = net_fallbacks(h->opponent, &f);
+            if (rc) { h->err = h->opponent->err; return rc; }
+            out->tower_fallbacks += f;
+        }
+    }
     return AZR_OK;
 }
 
@@ -1511,6 +1547,8 @@ extern "C" int azr_arena_start(azr_engine* h, int player1, int player2, int game
 {
     ENTER(h);
     if (player1 < 0 || player1 > 3 || player2 < 0 || player2 > 3 || games < 0) return AZR_E_INVALID_ARGUMENT;
+    if (mirror_games < AZR_MIRROR_OFF || mirror_games > AZR_MIRROR_CONCURRENT) { h->err = "azr_arena_start: mirror_games must be AZR_MIRROR_OFF / _SEQUENTIAL / _CONCURRENT"; return AZR_E_INVALID_ARGUMENT; }
+    if (mirror_games == AZR_MIRROR_CONCURRENT && h->d.G < 2) { h->err = "azr_arena_start: AZR_MIRROR_CONCURRENT needs at least 2 slots (a pair's halves play on slots 2j and 2j + 1)"; return AZR_E_INVALID_ARGUMENT; }
     if (player1 == player2 && (player1 == AZR_PLAYER_ALPHAZERO || player1 == AZR_PLAYER_ALPHAZERO_B)) {
         h->err = "azr_arena_start: two AlphaZero players need one tree each: use AZR_PLAYER_ALPHAZERO vs AZR_PLAYER_ALPHAZERO_B "
                  "(azr_arena_set_opponent_net(h, h) for the same network on both sides)";
@@ -1591,8 +1629,6 @@ extern "C" int azr_arena_run(azr_engine* h, int passes, int* finished_out)
     std::vector<uint32_t> st(h->d.G);
     HIPCHK(h, hipMemcpy2DAsync(st.data(), 4, &h->d.ctl[0].arena_state, sizeof(Ctl), 4, h->d.G, hipMemcpyDeviceToHost, h->stream));
     SYNC(h);
-    { int rcn = net_check(h); if (rcn) return rcn; }
-    if (h->opponent) { int rcn = net_check(h->opponent); if (rcn) { h->err = h->opponent->err; return rcn; } }
     int idle = 0;
     for (uint32_t v : st) idle += v == 2;
     if (finished_out) *finished_out = idle == h->d.G;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -9,7 +10,22 @@
 #include "../../include/azr.h"
 #include "azr_tree.hpp"
 
+// Test hooks.  Environment switches that select an older or alternative formulation of the same arithmetic (the parity tests compare it
+// with the default one as an independently written implementation), force a hand-off to give up, or stand in for a communicator exist
+// ONLY in libazr_hip_test.so — the same sources compiled with -DAZR_TEST_HOOKS by `make test` (csrc/Makefile), loaded by the tests that
+// need them.  The product library libazr_hip.so reads no environment variable and carries one path.
+#ifdef AZR_TEST_HOOKS
+#include <stdlib.h>
 namespace azr {
+inline const char* hook_env(const char* name) { return getenv(name); }
+}
+#else
+namespace azr {
+constexpr const char* hook_env(const char*) { return nullptr; }
+}
+#endif
+namespace azr {
+inline int hook_env_int(const char* name, int dflt) { const char* v = hook_env(name); return v ? atoi(v) : dflt; }
 
 constexpr int LEAF_STRIDE = 96;    // in88 padded to 96 B per game
 constexpr int PI_STRIDE = 44;      // pi[43] padded
@@ -132,7 +148,7 @@ int net_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, floa
 int net_forward_ex(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st);
 size_t net_param_count(int blocks);
 void net_init_random(float* flat, int blocks, uint64_t seed);
-int net_check(azr_engine* h);   // deferred device-side error words (read at the caller's synchronisation points)
+int net_fallbacks(azr_engine* h, unsigned long long* out);   // split-channel tower launches recomputed after a hand-off gave up
 // NET_F32X (azr_tower_fx.hip)
 int net_fx_alloc(azr_engine* h);
 void net_fx_free(azr_engine* h);

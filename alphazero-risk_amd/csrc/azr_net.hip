@@ -403,10 +403,12 @@ int azr::net_forward_ex(azr_engine* h, const uint8_t* d_in88, int in_stride, int
     return net_bf16_forward(h, d_in88, in_stride, n, d_pi, d_v, d_map, st);
 }
 
-namespace azr { int tower_sc_check(azr_engine* h); }   // azr_tower_sc.hip
-int azr::net_check(azr_engine* h)
+namespace azr { int tower_sc_fallbacks(azr_engine* h, unsigned long long* out); }   // azr_tower_sc.hip
+// launches of the split-channel tower that gave up a hand-off and were recomputed by the guarded launch behind them
+int azr::net_fallbacks(azr_engine* h, unsigned long long* out)
 {
-    if ((h->cfg.net_dtype == AZR_NET_BF16 || h->cfg.net_dtype == AZR_NET_F16) && h->net.bf16ctx) return tower_sc_check(h);
+    *out = 0;
+    if ((h->cfg.net_dtype == AZR_NET_BF16 || h->cfg.net_dtype == AZR_NET_F16) && h->net.bf16ctx) return tower_sc_fallbacks(h, out);
     return AZR_OK;
 }
 
@@ -514,6 +516,5 @@ extern "C" int azr_nn_predict(azr_engine* h, const void* in88, int n, float* pi,
         if (pi) for (int i = 0; i < m; i++) memcpy(pi + (size_t)(base + i) * 43, s_pi + (size_t)i * PI_STRIDE, 43 * 4);
         if (v) memcpy(v + base, s_v, (size_t)m * 4);
     }
-    if (rc == AZR_OK) rc = net_check(h);
     return rc;
 }

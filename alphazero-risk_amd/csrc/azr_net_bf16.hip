@@ -537,10 +537,16 @@ __global__ __launch_bounds__(1024 / NT, NT == 2 ? 2 : 1) void k_tower_bf16(const
                                                                            const float* __restrict__ hp,
                                                                            float* __restrict__ pi_out, float* __restrict__ v_out,
                                                                            unsigned long long* __restrict__ diag, int n_full,
-                                                                           const int* __restrict__ slot_map)
+                                                                           const int* __restrict__ slot_map, unsigned* __restrict__ guard)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int bid = blockIdx.x;
+    // guard != null: this launch stands behind a k_tower_sc launch of the same batch and runs only if that one raised its give-up word
+    // (a hand-off ran out of polls: its results are garbage) — every workgroup ends here otherwise; workgroup 0 counts the recompute
+    if (guard) {
+        if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(guard + SC_W_GIVEUP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) return;
+        if (bid == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(guard + SC_W_FALLBACKS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if constexpr (NB >= 2) {
         if (bid >= n_full) {
             tower_body<NB - 1, NT, F16>(lds, n_full * NB + (bid - n_full) * (NB - 1), in88, in_stride, n, stem_wp, tower_wp, fold, blocks, hp,
@@ -568,12 +574,12 @@ int net_bf16_alloc(azr_engine* h)
     HIPCHK(h, hipMemsetAsync(x->tower_wp, 0, ((size_t)2 * B * TOWER_LAYER_HALFS + MAX_RING * KSTRIDE * 8) * 2, h->stream));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<1, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<1>::LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<1, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Geo<1>::LDS_BYTES));
-    // test / measurement switch, read ONCE, here (never in the launch path): AZR_TOWER_SB = 0: the two-image kernel (one board per
-    // workgroup) for every launch — the independently written implementation the single-image tiles are compared with bit for bit;
-    // 1 (default): plan; 2 / 3 / 4: force the 4- / 2- / 3-board single-image tile
-    x->sb_mode = getenv("AZR_TOWER_SB") ? atoi(getenv("AZR_TOWER_SB")) : 1;
+    // test hooks (libazr_hip_test.so only, azr_internal.hpp; read ONCE, here, never in the launch path): AZR_TOWER_SB = 0: the two-image
+    // kernel (one board per workgroup) for every launch — the independently written implementation the single-image tiles are compared
+    // with bit for bit; 1 (default, and the product): plan; 2 / 3 / 4: force the 4- / 2- / 3-board single-image tile
+    x->sb_mode = hook_env_int("AZR_TOWER_SB", 1);
     // AZR_TOWER_SC=0: launches of <= 128 boards on k_tower_bf16<1> instead of the split-channel tower (A/B measurements, tests)
-    x->sc_mode = getenv("AZR_TOWER_SC") ? atoi(getenv("AZR_TOWER_SC")) : 1;
+    x->sc_mode = hook_env_int("AZR_TOWER_SC", 1);
     int rc = tower_sc_init(h);
     if (rc) return rc;
     return tower_sb_init(h);
@@ -711,19 +717,24 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
         if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
         return rc;
     }
+    unsigned* guard = nullptr;
     if (x->sb_mode != 0 && x->sc_mode != 0 && n <= 128) {   // up to 128 boards: a board pair's channels split over 4 workgroups (azr_tower_sc.hip)
         int rc = tower_sc_launch(h, d_in88, in_stride, n, d_pi, d_v, d_map, st);
         if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
-        return rc;
+        if (rc) return rc;
+        // ... and right behind it, in stream order, the one-board-per-workgroup kernel under the launch's give-up word: it recomputes the
+        // batch if (and only if) a hand-off of the persistent launch ran out of polls; otherwise its n workgroups end at their first
+        // instruction.  Later tree steps on this stream therefore never see the garbage of a launch that gave up.
+        guard = x->sc_counters;
     }
     // AZR_TOWER_SB=0 / AZR_TOWER_SC=0: one board per workgroup for the whole net, two ping-pong images, 8 waves x 32 channels
     if (x->f16)
         hipLaunchKernelGGL((k_tower_bf16<1, 2, true>), dim3(n), dim3(512), Geo<1>::LDS_BYTES, st, d_in88, in_stride, n, x->stem_wp, x->tower_wp,
-                           (const float*)x->fold16, B, net_head_params(h), d_pi, d_v, x->diag, n, d_map);
+                           (const float*)x->fold16, B, net_head_params(h), d_pi, d_v, x->diag, n, d_map, guard);
     else
         hipLaunchKernelGGL((k_tower_bf16<1, 2, false>), dim3(n), dim3(512), Geo<1>::LDS_BYTES, st, d_in88, in_stride, n, x->stem_wp, x->tower_wp, fold, B,
-                           net_head_params(h), d_pi, d_v, x->diag, n, d_map);
-    if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
+                           net_head_params(h), d_pi, d_v, x->diag, n, d_map, guard);
+    if (h->pe_tower1 && !guard) hipEventRecord(h->pe_tower1, st);
     HIPCHK(h, hipGetLastError());
     return AZR_OK;
 }

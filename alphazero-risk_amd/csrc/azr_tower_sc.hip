@@ -17,8 +17,10 @@
 //     epilogue -> own channels of the new image: write-through (sc1) stores to the exchange image of this layer's parity
 //     every wave drains its stores (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane adds 1 to the pair's counter (agent scope)
 //     own channels -> LDS image; the next layer's first weight fragments are requested;  one lane polls the counter until all CGN
-//     workgroups of the pair have arrived at this layer (relaxed sc1 loads, s_sleep, bounded: a spin that runs out sets the error
-//     word and the launch ends with garbage, never hangs), workgroup barrier, the partners' channels are fetched with sc1 loads
+//     workgroups of the pair have arrived at this layer (relaxed sc1 loads, s_sleep, bounded: a spin that runs out raises the
+//     launch's GIVE-UP word in device memory — the launch then ends with garbage, never hangs, and the guarded k_tower_bf16<1> launch
+//     queued right behind it on the same stream recomputes the whole batch, see tower_sc_launch), workgroup barrier, the partners'
+//     channels are fetched with sc1 loads
 //     (they never hit this CU's L1: no acquire fence needed for write-through, drained stores) into the LDS image, barrier.
 // (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility": the drained-sc1-stores + counter form.)
 // 3.2 us per layer; where the four workgroups of a pair run on one XCD (checked at run time through HW_REG_XCC_ID; the block ids are laid
@@ -68,6 +70,8 @@ constexpr int IMG = (ZR + 1) * ROWB;                  // the pair's activation i
 constexpr uint32_t EX_PAIR_BYTES = ZR * NF * 2;       // one pair's exchange image: [96 rows][256] bf16, no pad
 constexpr int AUX_SC1 = 16;                           // cache-policy bits of the raw buffer builtins: sc1 (write-through store / L1-bypassing load)
 constexpr unsigned SPIN_LIMIT = 1u << 21;             // polls of a hand-off before the launch gives up (~1 s)
+constexpr int W_GIVEUP = 2 * MAX_PAIRS;               // word of the counter block: raised by a hand-off that ran out of polls (zeroed per launch)
+constexpr int W_FALLBACKS = 2 * MAX_PAIRS + 1;        // ... launches the guarded one-board-per-workgroup kernel had to recompute (never zeroed)
 
 // LDS map (dynamic): image | stem features | NNInputData images | tables | heads scratch
 constexpr int FEAT_OFF = IMG;
@@ -142,13 +146,12 @@ __device__ __forceinline__ void sc_tap(const uint8_t* bufX, const uint8_t* tr_c,
     for (int i = 0; i < MTW; i++) ap[i] = np[i];
 }
 
-// The all-to-all at the end of a layer (epoch = 1 for the stem, 2 .. 2B + 1 for the conv layers), in two halves.
-// publish: this wave's part o[i][nt] of the workgroup's channels goes to the exchange image of the epoch's parity (write-through),
-// every wave drains its stores, barrier, ONE lane counts the workgroup in; then the own channels go into the LDS image (nobody reads
-// the old one any more).
+// The all-to-all at the end of a layer (epoch = 1 for the stem, 2 .. 2B + 1 for the conv layers).  The pieces that depend on the wave's
+// row half (MH: which row tiles, which pad rows) contain NO barrier; the barriers, the count and the poll live in hand_off() below,
+// code that all four waves of the workgroup execute at the same program counter.
+// publish_stores: this wave's part o[i][nt] of the workgroup's channels goes to the exchange image of the epoch's parity.
 template <int MH>
-__device__ __forceinline__ void publish(uint8_t* bufX, const uint2 (&o)[MTW][NTW], int epoch, int pair, int ct0, int c, int g, int tid,
-                                        const __amdgpu_buffer_rsrc_t ex, unsigned* counter, bool same_xcd)
+__device__ __forceinline__ void publish_stores(const uint2 (&o)[MTW][NTW], int epoch, int pair, int ct0, int c, int g, const __amdgpu_buffer_rsrc_t ex, bool same_xcd)
 {
     const uint32_t img_off = (uint32_t)(pair * 2 + (epoch & 1)) * EX_PAIR_BYTES;
 #pragma unroll
@@ -164,9 +167,11 @@ __device__ __forceinline__ void publish(uint8_t* bufX, const uint2 (&o)[MTW][NTW
             else __builtin_amdgcn_raw_buffer_store_b64(u32x2{o[i][nt].x, o[i][nt].y}, ex, off, 0, AUX_SC1);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its stores
-    __syncthreads();                                    // ... and every wave has read the old image for the last time
-    if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// own_to_lds: the own channels go into the LDS image (nobody reads the old one any more: called behind hand_off's first barrier)
+template <int MH>
+__device__ __forceinline__ void own_to_lds(uint8_t* bufX, const uint2 (&o)[MTW][NTW], int ct0, int c, int g)
+{
     const uint32_t eoff = (uint32_t)(c * ROWB + (ct0 * 16 + g * 4) * 2);
 #pragma unroll
     for (int i = 0; i < MTW; i++) {
@@ -176,11 +181,20 @@ __device__ __forceinline__ void publish(uint8_t* bufX, const uint2 (&o)[MTW][NTW
         for (int nt = 0; nt < NTW; nt++) *reinterpret_cast<uint2*>(bufX + eoff + mt * 16 * ROWB + nt * 32) = o[i][nt];
     }
 }
+// count_in: every storing wave has drained its stores (s_waitcnt vmcnt(0)) before this barrier; behind it ONE lane counts the workgroup in
+__device__ __forceinline__ void count_in(int tid, unsigned* counter)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY storing wave drains its stores
+    __syncthreads();                                    // ... and every wave has read the old image for the last time
+    if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // gather: ONE lane polls the pair's counter (relaxed agent loads, bounded), barrier, the partners' channels come into the LDS image
 // through sc1 loads — loads that never hit this CU's L1, of bytes that were stored write-through and drained before the count: the
 // form that needs no acquire fence (MI355X_MICROARCH.md, visibility section, valid forms, first row of the table).  Pad rows are
-// stored by nobody and fetched by nobody.
-__device__ __forceinline__ void gather(uint8_t* bufX, int epoch, int pair, int cg, int tid, const __amdgpu_buffer_rsrc_t ex, unsigned* counter, unsigned* err)
+// stored by nobody and fetched by nobody.  A poll that runs out of spins raises the launch's give-up word (device memory, agent scope)
+// and goes on with whatever the image holds; once the word is up nobody waits any more (the launch is lost: it only has to end).
+__device__ __forceinline__ void gather(uint8_t* bufX, int epoch, int pair, int cg, int tid, const __amdgpu_buffer_rsrc_t ex, unsigned* counter, unsigned* giveup,
+                                       unsigned spin_limit)
 {
     constexpr int UNITS = ZR * 32 / THREADS;   // 16-byte units per thread over the whole [96][512 B] image: rows (tid >> 5) + 8 i, segment tid & 31
     const uint32_t img_off = (uint32_t)(pair * 2 + (epoch & 1)) * EX_PAIR_BYTES;
@@ -188,8 +202,10 @@ __device__ __forceinline__ void gather(uint8_t* bufX, int epoch, int pair, int c
         const unsigned want = (unsigned)(CGN * epoch);
         unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            if (spins >= spin_limit) { __hip_atomic_store(giveup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if ((spins & 255u) == 255u && __hip_atomic_load(giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            spins++;
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }   // (the error word is host memory)
         }
     }
     __syncthreads();
@@ -208,12 +224,96 @@ __device__ __forceinline__ void gather(uint8_t* bufX, int epoch, int pair, int c
     __syncthreads();
 }
 
-
-// stem + residual tower of one computing wave (row half MH of the pair); false = this workgroup is done (not channel group 0)
+// ---- the two pieces of a wave's work that depend on its row half MH (compile-time tile lists and skip masks); no barrier inside
+// stem: 3x3 conv 13 -> 256 (this wave's rows and channels), conv_bn over the board row + ReLU -> o (= the first block's input, res)
 template <int MH, bool F16>
-__device__ __forceinline__ bool sc_wave(uint8_t* lds, int pair, int cg, int blocks, const uint16_t* __restrict__ stem_wp, const uint16_t* __restrict__ tower_wp,
-                                        uint32_t tower_bytes, const float* __restrict__ fold, uint8_t* __restrict__ ex_base, uint32_t ex_bytes_total,
-                                        unsigned* counter, unsigned* err)
+__device__ __forceinline__ void stem_half(const uint8_t* bufF, const uint8_t* taprow, const uint16_t* rowcell, const uint16_t* __restrict__ stem_wp,
+                                          const float* __restrict__ fold, int ct0, int lane, int c, int g, f32x4 (&acc)[MTW][NTW], uint2 (&o)[MTW][NTW],
+                                          uint2 (&res)[MTW][NTW])
+{
+#pragma unroll
+    for (int i = 0; i < MTW; i++)
+#pragma unroll
+        for (int nt = 0; nt < NTW; nt++) acc[i][nt] = f32x4{0, 0, 0, 0};
+    const s16x8* wp = reinterpret_cast<const s16x8*>(stem_wp) + (size_t)ct0 * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < STEM_KS; ks++) {
+        const int tap = 2 * ks + (g >> 1);
+        s16x8 b[NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; nt++) b[nt] = wp[(size_t)ks * FRAGS_PER_KSTEP * 64 + nt * 64];
+#pragma unroll
+        for (int i = 0; i < MTW; i++) {
+            const int row = taprow[tap * ZR + tile_of<MH>(i) * 16 + c];
+            const s16x8 av = lds16(bufF + row * FROWB + (g & 1) * 16);
+#pragma unroll
+            for (int nt = 0; nt < NTW; nt++)
+                acc[i][nt] = El<F16>::mfma(b[nt], av, acc[i][nt]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MTW; i++) {
+        const int ci = rowcell[tile_of<MH>(i) * 16 + c];
+        const int y = ci == 0xffff ? 0 : (ci & 15);
+        const float sc = fold[y], sh = fold[7 + y];
+#pragma unroll
+        for (int nt = 0; nt < NTW; nt++) {
+            o[i][nt] = bn_relu_pack<false, F16>(acc[i][nt], float4{sc, sc, sc, sc}, float4{sh, sh, sh, sh}, uint2{0, 0});
+            res[i][nt] = o[i][nt];
+        }
+    }
+}
+
+// one conv layer of the tower for this wave's tile: 72 k-steps (the ring runs ahead inside the layer) and the epilogue -> o (and res
+// behind the second conv of a block)
+template <int MH, bool F16>
+__device__ __forceinline__ void layer_half(const uint8_t* bufX, const uint8_t* tr_c, uint32_t g16, const __amdgpu_buffer_rsrc_t wsrc, uint32_t loff, uint32_t wk,
+                                           bool second, const float4 (&sc)[NTW], const float4 (&sh)[NTW], u32x4 (&bq)[RING][NTW],
+                                           f32x4 (&acc)[MTW][NTW], uint2 (&o)[MTW][NTW], uint2 (&res)[MTW][NTW])
+{
+#pragma unroll
+    for (int i = 0; i < MTW; i++)
+#pragma unroll
+        for (int nt = 0; nt < NTW; nt++) acc[i][nt] = f32x4{0, 0, 0, 0};
+    uint32_t ap[MTW];
+    s16x8 a[MTW];
+    {
+        constexpr uint32_t m0 = skip_mask<NB>(0);
+#pragma unroll
+        for (int i = 0; i < MTW; i++) {
+            ap[i] = (uint32_t)tr_c[tile_of<MH>(i) * 16] * ROWB + g16;
+            if (!((m0 >> tile_of<MH>(i)) & 1u)) a[i] = lds16(bufX + ap[i]);
+        }
+    }
+    sc_tap<MH, 0, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+    sc_tap<MH, 1, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+    sc_tap<MH, 2, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+    sc_tap<MH, 3, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+    sc_tap<MH, 4, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+    sc_tap<MH, 5, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+    sc_tap<MH, 6, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+    sc_tap<MH, 7, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+    sc_tap<MH, 8, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+    if (second) {    // second conv of a block: + shortcut (the block's input), and this output is the next block's input
+#pragma unroll
+        for (int i = 0; i < MTW; i++)
+#pragma unroll
+            for (int nt = 0; nt < NTW; nt++) { o[i][nt] = bn_relu_pack<true, F16>(acc[i][nt], sc[nt], sh[nt], res[i][nt]); res[i][nt] = o[i][nt]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MTW; i++)
+#pragma unroll
+            for (int nt = 0; nt < NTW; nt++) o[i][nt] = bn_relu_pack<false, F16>(acc[i][nt], sc[nt], sh[nt], uint2{0, 0});
+    }
+}
+
+// stem + residual tower of the workgroup.  Waves 0, 1 take the row tiles 0 - 2, waves 2, 3 the tiles 3 - 5 (mh; the per-half pieces
+// above are selected by a wave-uniform branch); everything that synchronises the workgroup — count_in's and gather's barriers, the
+// count, the poll — is HERE, in code common to all four waves.  false = this workgroup is done (not channel group 0).
+template <bool F16>
+__device__ __forceinline__ bool sc_run(uint8_t* lds, int pair, int cg, int blocks, const uint16_t* __restrict__ stem_wp, const uint16_t* __restrict__ tower_wp,
+                                       uint32_t tower_bytes, const float* __restrict__ fold, uint8_t* __restrict__ ex_base, uint32_t ex_bytes_total,
+                                       unsigned* counter, unsigned* giveup, unsigned spin_limit, int force_wt)
 {
     // which XCD this workgroup runs on: every workgroup of the pair adds 1 to the 3-bit field of its XCC in the pair's word before its
     // stem stores are drained and counted; behind the stem's hand-off the word says whether all four share one XCD (speed only: the
@@ -226,6 +326,7 @@ __device__ __forceinline__ bool sc_wave(uint8_t* lds, int pair, int cg, int bloc
     const uint8_t* taprow = lds + TAPROW_OFF;
     const uint16_t* rowcell = reinterpret_cast<const uint16_t*>(lds + ROWCELL_OFF);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    const bool mh = (wave >> 1) != 0;                   // wave-uniform: this wave's row half
     const int ct0 = cg * 4 + (wave & 1) * NTW;          // this wave's first 16-channel column tile
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(tower_wp), (short)0, (int)tower_bytes, 0x00020000);
     const uint32_t loff = (uint32_t)(ct0 * 64 + lane) * 16u;
@@ -239,46 +340,17 @@ __device__ __forceinline__ bool sc_wave(uint8_t* lds, int pair, int cg, int bloc
     f32x4 acc[MTW][NTW];
     uint2 res[MTW][NTW];     // the block input of this wave's (cell, 4-channel) elements, packed bf16 = the residual operand
     uint2 o[MTW][NTW];
-
-    // ---- stem: 3x3 conv 13 -> 256 (this wave's rows and channels), conv_bn over the board row + ReLU
-    {
-#pragma unroll
-        for (int i = 0; i < MTW; i++)
-#pragma unroll
-            for (int nt = 0; nt < NTW; nt++) acc[i][nt] = f32x4{0, 0, 0, 0};
-        const s16x8* wp = reinterpret_cast<const s16x8*>(stem_wp) + (size_t)ct0 * 64 + lane;
-#pragma unroll
-        for (int ks = 0; ks < STEM_KS; ks++) {
-            const int tap = 2 * ks + (g >> 1);
-            s16x8 b[NTW];
-#pragma unroll
-            for (int nt = 0; nt < NTW; nt++) b[nt] = wp[(size_t)ks * FRAGS_PER_KSTEP * 64 + nt * 64];
-#pragma unroll
-            for (int i = 0; i < MTW; i++) {
-                const int row = taprow[tap * ZR + tile_of<MH>(i) * 16 + c];
-                const s16x8 av = lds16(bufF + row * FROWB + (g & 1) * 16);
-#pragma unroll
-                for (int nt = 0; nt < NTW; nt++)
-                    acc[i][nt] = El<F16>::mfma(b[nt], av, acc[i][nt]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < MTW; i++) {
-            const int ci = rowcell[tile_of<MH>(i) * 16 + c];
-            const int y = ci == 0xffff ? 0 : (ci & 15);
-            const float sc = fold[y], sh = fold[7 + y];
-#pragma unroll
-            for (int nt = 0; nt < NTW; nt++) {
-                o[i][nt] = bn_relu_pack<false, F16>(acc[i][nt], float4{sc, sc, sc, sc}, float4{sh, sh, sh, sh}, uint2{0, 0});
-                res[i][nt] = o[i][nt];
-            }
-        }
-    }
     const __amdgpu_buffer_rsrc_t ex = __builtin_amdgcn_make_buffer_rsrc(ex_base, (short)0, (int)ex_bytes_total, 0x00020000);
-    publish<MH>(bufX, o, 1, pair, ct0, c, g, tid, ex, counter, false);
-    gather(bufX, 1, pair, cg, tid, ex, counter, err);
-    // (thread 0's add above was drained with the stem's stores — vmcnt(0) in publish — before this workgroup was counted in)
-    const bool same_xcd = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(xccw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == (int)((unsigned)CGN << (3u * xcc));
+
+    if (mh) stem_half<1, F16>(bufF, taprow, rowcell, stem_wp, fold, ct0, lane, c, g, acc, o, res);
+    else stem_half<0, F16>(bufF, taprow, rowcell, stem_wp, fold, ct0, lane, c, g, acc, o, res);
+    if (mh) publish_stores<1>(o, 1, pair, ct0, c, g, ex, false); else publish_stores<0>(o, 1, pair, ct0, c, g, ex, false);
+    count_in(tid, counter);
+    if (mh) own_to_lds<1>(bufX, o, ct0, c, g); else own_to_lds<0>(bufX, o, ct0, c, g);
+    gather(bufX, 1, pair, cg, tid, ex, counter, giveup, spin_limit);
+    // (thread 0's add above was drained with the stem's stores — vmcnt(0) in count_in — before this workgroup was counted in)
+    const bool same_xcd = !force_wt &&
+        __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(xccw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == (int)((unsigned)CGN << (3u * xcc));
 
     // ---- residual tower
     const uint8_t* tr_c = taprow + c;
@@ -286,48 +358,18 @@ __device__ __forceinline__ bool sc_wave(uint8_t* lds, int pair, int cg, int bloc
     const int layers = 2 * blocks;
     uint32_t wk = 0;
     for (int L = 0; L < layers; L++) {
-#pragma unroll
-        for (int i = 0; i < MTW; i++)
-#pragma unroll
-            for (int nt = 0; nt < NTW; nt++) acc[i][nt] = f32x4{0, 0, 0, 0};
         float4 sc[NTW], sh[NTW];
 #pragma unroll
         for (int nt = 0; nt < NTW; nt++) {
             sc[nt] = *reinterpret_cast<const float4*>(fold + 14 + (size_t)L * 2 * NF + (ct0 + nt) * 16 + g * 4);
             sh[nt] = *reinterpret_cast<const float4*>(fold + 14 + (size_t)L * 2 * NF + NF + (ct0 + nt) * 16 + g * 4);
         }
-        uint32_t ap[MTW];
-        s16x8 a[MTW];
-        {
-            constexpr uint32_t m0 = skip_mask<NB>(0);
-#pragma unroll
-            for (int i = 0; i < MTW; i++) {
-                ap[i] = (uint32_t)tr_c[tile_of<MH>(i) * 16] * ROWB + g16;
-                if (!((m0 >> tile_of<MH>(i)) & 1u)) a[i] = lds16(bufX + ap[i]);
-            }
-        }
-        sc_tap<MH, 0, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        sc_tap<MH, 1, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        sc_tap<MH, 2, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        sc_tap<MH, 3, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        sc_tap<MH, 4, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        sc_tap<MH, 5, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        sc_tap<MH, 6, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        sc_tap<MH, 7, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
-        sc_tap<MH, 8, F16>(bufX, tr_c, g16, wsrc, loff, wk, bq, acc, a, ap);
+        if (mh) layer_half<1, F16>(bufX, tr_c, g16, wsrc, loff, wk, (L & 1) != 0, sc, sh, bq, acc, o, res);
+        else layer_half<0, F16>(bufX, tr_c, g16, wsrc, loff, wk, (L & 1) != 0, sc, sh, bq, acc, o, res);
         wk += (uint32_t)(9 * KS_PER_TAP) * (uint32_t)KBYTES;
-        if (L & 1) {    // second conv of a block: + shortcut (the block's input), and this output is the next block's input
-#pragma unroll
-            for (int i = 0; i < MTW; i++)
-#pragma unroll
-                for (int nt = 0; nt < NTW; nt++) { o[i][nt] = bn_relu_pack<true, F16>(acc[i][nt], sc[nt], sh[nt], res[i][nt]); res[i][nt] = o[i][nt]; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < MTW; i++)
-#pragma unroll
-                for (int nt = 0; nt < NTW; nt++) o[i][nt] = bn_relu_pack<false, F16>(acc[i][nt], sc[nt], sh[nt], uint2{0, 0});
-        }
-        publish<MH>(bufX, o, L + 2, pair, ct0, c, g, tid, ex, counter, same_xcd);
+        if (mh) publish_stores<1>(o, L + 2, pair, ct0, c, g, ex, same_xcd); else publish_stores<0>(o, L + 2, pair, ct0, c, g, ex, same_xcd);
+        count_in(tid, counter);
+        if (mh) own_to_lds<1>(bufX, o, ct0, c, g); else own_to_lds<0>(bufX, o, ct0, c, g);
         if (L == layers - 1) {
             if (cg != 0) return false;   // after the last layer only channel group 0 goes on (the heads)
         } else {
@@ -338,7 +380,7 @@ __device__ __forceinline__ bool sc_wave(uint8_t* lds, int pair, int cg, int bloc
                 for (int nt = 0; nt < NTW; nt++)
                     bq[ks][nt] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, loff + nt * 1024, (int)(wk + (uint32_t)ks * (uint32_t)KBYTES), 0);
         }
-        gather(bufX, L + 2, pair, cg, tid, ex, counter, err);
+        gather(bufX, L + 2, pair, cg, tid, ex, counter, giveup, spin_limit);
     }
     return true;
 }
@@ -349,7 +391,7 @@ __global__ __launch_bounds__(THREADS) void k_tower_sc(const uint8_t* __restrict_
                                                        const float* __restrict__ fold, int blocks, const float* __restrict__ hp,
                                                        float* __restrict__ pi_out, float* __restrict__ v_out, const int* __restrict__ slot_map,
                                                        uint8_t* __restrict__ ex_base, uint32_t ex_bytes_total, unsigned* __restrict__ counters,
-                                                       unsigned* __restrict__ err)
+                                                       unsigned spin_limit, int force_wt)
 {
     // block id -> (pair, channel group): the CGN workgroups of a pair are 8 ids apart
     const int grp = blockIdx.x / (8 * CGN), r = blockIdx.x % (8 * CGN), cg = r / 8, pair = grp * 8 + (r & 7);
@@ -401,11 +443,9 @@ __global__ __launch_bounds__(THREADS) void k_tower_sc(const uint8_t* __restrict_
     for (int i = tid; i < ZR * (ROWB / 4); i += THREADS) reinterpret_cast<uint32_t*>(bufX)[i] = 0;
     __syncthreads();
 
-    // ---- stem and tower: waves 0, 1 take the row tiles 0, 3, 4, waves 2, 3 the tiles 1, 2, 5 (the skip masks are compile-time per half)
-    unsigned* counter = counters + pair;
-    const bool heads = (wave >> 1) ? sc_wave<1, F16>(lds, pair, cg, blocks, stem_wp, tower_wp, tower_bytes, fold, ex_base, ex_bytes_total, counter, err)
-                                   : sc_wave<0, F16>(lds, pair, cg, blocks, stem_wp, tower_wp, tower_bytes, fold, ex_base, ex_bytes_total, counter, err);
-    if (!heads) return;
+    // ---- stem and tower
+    if (!sc_run<F16>(lds, pair, cg, blocks, stem_wp, tower_wp, tower_bytes, fold, ex_base, ex_bytes_total, counters + pair, counters + W_GIVEUP, spin_limit, force_wt))
+        return;
 
     // ---- both heads for the pair (k_tower_sb's fused heads), channel group 0 only
     {
@@ -493,12 +533,14 @@ int tower_sc_init(azr_engine* h)
     const size_t ex_bytes = (size_t)2 * MAX_PAIRS * EX_PAIR_BYTES;   // [pair][parity of the epoch][96 rows][256] bf16
     HIPCHK(h, hipMalloc((void**)&x->sc_ex, ex_bytes));
     HIPCHK(h, hipMemsetAsync(x->sc_ex, 0, ex_bytes, h->stream));
-    HIPCHK(h, hipMalloc((void**)&x->sc_counters, (2 * MAX_PAIRS + 4) * sizeof(unsigned)));   // [MAX_PAIRS] arrival counters | [MAX_PAIRS] XCC words | error word
-    HIPCHK(h, hipMemsetAsync(x->sc_counters, 0, (2 * MAX_PAIRS + 4) * sizeof(unsigned), h->stream));
-    // the error word lives in mapped host memory: written by a kernel only when a hand-off gives up, read by the host for nothing
-    HIPCHK(h, hipHostMalloc((void**)&x->sc_err_host, 16, hipHostMallocMapped));
-    x->sc_err_host[0] = 0;
-    HIPCHK(h, hipHostGetDevicePointer((void**)&x->sc_err_dev, x->sc_err_host, 0));
+    // [MAX_PAIRS] arrival counters | [MAX_PAIRS] XCC words | give-up word of the running launch | count of recomputed launches
+    static_assert(W_GIVEUP == SC_W_GIVEUP && W_FALLBACKS == SC_W_FALLBACKS, "the guarded fallback launch (azr_net_bf16.hip) reads these words");
+    HIPCHK(h, hipMalloc((void**)&x->sc_counters, SC_WORDS * sizeof(unsigned)));
+    HIPCHK(h, hipMemsetAsync(x->sc_counters, 0, SC_WORDS * sizeof(unsigned), h->stream));
+    // test hooks (libazr_hip_test.so only): AZR_TOWER_SC_SPIN = polls before a hand-off gives up (0: every hand-off whose partners are
+    // not there yet gives up at once — forces the recompute path); AZR_TOWER_SC_WT=1: never the plain-store form of a same-XCD pair
+    x->sc_spin_limit = (unsigned)hook_env_int("AZR_TOWER_SC_SPIN", (int)SPIN_LIMIT);
+    x->sc_force_wt = hook_env_int("AZR_TOWER_SC_WT", 0);
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_sc<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_sc<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     return AZR_OK;
@@ -510,13 +552,12 @@ void tower_sc_free(azr_engine* h)
     if (!x) return;
     if (x->sc_ex) hipFree(x->sc_ex);
     if (x->sc_counters) hipFree(x->sc_counters);
-    if (x->sc_err_host) hipHostFree(x->sc_err_host);
-    x->sc_err_host = x->sc_err_dev = nullptr;
     x->sc_ex = nullptr;
     x->sc_counters = nullptr;
 }
 
-// the whole net for n <= 128 boards in one persistent launch of 4 workgroups per board pair
+// the whole net for n <= 128 boards in one persistent launch of 4 workgroups per board pair.  The caller queues the guarded
+// one-board-per-workgroup launch right behind it (net_bf16_forward): if a hand-off of this launch gave up, that one recomputes the batch.
 int tower_sc_launch(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st)
 {
     if (n < 1 || n > 2 * MAX_PAIRS) { h->err = "tower_sc_launch: 1..128 boards"; return AZR_E_INVALID_ARGUMENT; }
@@ -525,25 +566,28 @@ int tower_sc_launch(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, 
     const int wgs = ((pairs + 7) / 8) * 8 * CGN;     // whole groups of 8 pairs (ids of a pair's workgroups are 8 apart)
     const uint32_t tower_bytes = (uint32_t)(((size_t)2 * B * TOWER_LAYER_HALFS + MAX_RING * KSTRIDE * 8) * 2);
     const uint32_t ex_bytes = (uint32_t)((size_t)2 * MAX_PAIRS * EX_PAIR_BYTES);
-    // the arrival counters count within ONE launch: zeroed ahead of it, in stream order
-    HIPCHK(h, hipMemsetAsync(x->sc_counters, 0, 2 * MAX_PAIRS * sizeof(unsigned), st));
+    // the arrival counters and the give-up word count within ONE launch: zeroed ahead of it, in stream order
+    HIPCHK(h, hipMemsetAsync(x->sc_counters, 0, (W_GIVEUP + 1) * sizeof(unsigned), st));
     if (x->f16)
         hipLaunchKernelGGL(k_tower_sc<true>, dim3(wgs), dim3(THREADS), LDS_BYTES, st, d_in88, in_stride, n, pairs, x->stem_wp, x->tower_wp, tower_bytes, (const float*)x->fold16, B,
-                           net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_err_dev);
+                           net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_spin_limit, x->sc_force_wt);
     else
         hipLaunchKernelGGL(k_tower_sc<false>, dim3(wgs), dim3(THREADS), LDS_BYTES, st, d_in88, in_stride, n, pairs, x->stem_wp, x->tower_wp, tower_bytes, net_fold(h), B,
-                           net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_err_dev);
+                           net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_spin_limit, x->sc_force_wt);
     HIPCHK(h, hipGetLastError());
     return AZR_OK;
 }
 
-// has a hand-off of an earlier launch run out of polls?  (read at the caller's synchronisation points)
-int tower_sc_check(azr_engine* h)
+// launches of the split-channel tower that gave up and were recomputed by the guarded launch behind them, since the handle was created
+int tower_sc_fallbacks(azr_engine* h, unsigned long long* out)
 {
     Bf16Net* x = bf16net(h);
-    if (!x || !x->sc_err_host) return AZR_OK;
-    const unsigned e = *reinterpret_cast<volatile unsigned*>(x->sc_err_host);   // (the caller has synchronised the stream)
-    if (e) { h->err = "k_tower_sc: a workgroup waited for its pair longer than the spin limit (the launch was not fully resident?)"; return AZR_E_HIP; }
+    unsigned v = 0;
+    if (x && x->sc_counters) {
+        HIPCHK(h, hipMemcpyAsync(&v, x->sc_counters + W_FALLBACKS, sizeof v, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    *out = v;
     return AZR_OK;
 }
 

@@ -28,6 +28,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <random>
 #include <sstream>
 #include <string>
@@ -1880,13 +1881,19 @@ __global__ void t_adam(float* __restrict__ w, const float* __restrict__ g, float
 // host
 // =====================================================================================================================
 // conv GEMM arithmetic: split bf16 (default; 6-pass forward, 3-pass backward) or the fp32 MFMA (AZR_TRAIN_GEMM=f32)
-bool g_gemm_bf16x3 = true;
+// (all five are test hooks: run-time switches in libazr_hip_test.so, compile-time constants in the product library)
+#ifdef AZR_TEST_HOOKS
+#define AZR_HOOK_FLAG bool
+#else
+#define AZR_HOOK_FLAG constexpr bool
+#endif
+AZR_HOOK_FLAG g_gemm_bf16x3 = true;
 // forward conv arithmetic: fp16 pairs, 3 passes (default) or three bf16 parts, 6 passes (AZR_TRAIN_FWD=bf16)
-bool g_fwd_f16 = true;
+AZR_HOOK_FLAG g_fwd_f16 = true;
 constexpr float FWD_WSCALE = 1024.0f;   // the packed forward kernels are 2^10 * W: |w| < 64 stays inside fp16, a weight of 1e-4 keeps a normal low part
-bool g_fuse_bwd = true;
-bool g_conv_q = true;       // t_conv_q for batches of up to 128 records (AZR_TRAIN_CONVQ=0: t_conv_rs at every size)
-bool g_fuse_apply = true;   // t_conv_rs<.., PRO>: the normalise kernels (t_bn_apply / t_bn_bwd_apply) computed in the consuming conv's staging path (AZR_TRAIN_FUSE_APPLY=0: separate kernels; same bits)   // t_conv_rs<2, 2, 1>: shortcut add + BN-backward stage 1 in the backward-data conv's epilogue (AZR_TRAIN_FUSE=0: separate kernels)
+AZR_HOOK_FLAG g_fuse_bwd = true;
+AZR_HOOK_FLAG g_conv_q = true;       // t_conv_q for batches of up to 128 records (AZR_TRAIN_CONVQ=0: t_conv_rs at every size)
+AZR_HOOK_FLAG g_fuse_apply = true;   // t_conv_rs<.., PRO>: the normalise kernels (t_bn_apply / t_bn_bwd_apply) computed in the consuming conv's staging path (AZR_TRAIN_FUSE_APPLY=0: separate kernels; same bits)   // t_conv_rs<2, 2, 1>: shortcut add + BN-backward stage 1 in the backward-data conv's epilogue (AZR_TRAIN_FUSE=0: separate kernels)
 
 struct TrainCtx {
     int BS = 0, blocks = 0, M = 0, L = 0, R = 0, nz = 0, kchunk = 0;
@@ -1964,11 +1971,13 @@ int ctx_ensure(azr_engine* h, int BS)
     TrainCtx* c = ctx_of(h);
     if (c && c->BS == BS) return AZR_OK;
     // tuning switch, read when a training context is (re)built — never in the step path
-    g_gemm_bf16x3 = !(getenv("AZR_TRAIN_GEMM") && strcmp(getenv("AZR_TRAIN_GEMM"), "f32") == 0);
-    g_fuse_bwd = !(getenv("AZR_TRAIN_FUSE") && atoi(getenv("AZR_TRAIN_FUSE")) == 0);
-    g_fwd_f16 = !(getenv("AZR_TRAIN_FWD") && strcmp(getenv("AZR_TRAIN_FWD"), "bf16") == 0);
-    g_fuse_apply = !(getenv("AZR_TRAIN_FUSE_APPLY") && atoi(getenv("AZR_TRAIN_FUSE_APPLY")) == 0);
-    g_conv_q = !(getenv("AZR_TRAIN_CONVQ") && atoi(getenv("AZR_TRAIN_CONVQ")) == 0);
+#ifdef AZR_TEST_HOOKS
+    g_gemm_bf16x3 = !(hook_env("AZR_TRAIN_GEMM") && strcmp(hook_env("AZR_TRAIN_GEMM"), "f32") == 0);
+    g_fuse_bwd = hook_env_int("AZR_TRAIN_FUSE", 1) != 0;
+    g_fwd_f16 = !(hook_env("AZR_TRAIN_FWD") && strcmp(hook_env("AZR_TRAIN_FWD"), "bf16") == 0);
+    g_fuse_apply = hook_env_int("AZR_TRAIN_FUSE_APPLY", 1) != 0;
+    g_conv_q = hook_env_int("AZR_TRAIN_CONVQ", 1) != 0;
+#endif
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(t_wgrad_rs), hipFuncAttributeMaxDynamicSharedMemorySize, Wg::LDS_BYTES));
     // a different batch size rebuilds the activation slabs but keeps the optimiser state
     std::vector<float> keep_m, keep_v;
@@ -2088,17 +2097,21 @@ struct RcclApi {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
 };
-RcclApi* rccl_api()
+static void rccl_bind(RcclApi& api);
+RcclApi* rccl_api()   // bound once, whichever host thread asks first (the host CLI runs one thread per GPU)
 {
     static RcclApi api;
-    static bool tried = false;
-    if (tried) return &api;
-    tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_bind(api); });
+    return &api;
+}
+static void rccl_bind(RcclApi& api)
+{
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (api.lib) break;
     }
-    if (!api.lib) { api.err = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return &api; }
+    if (!api.lib) { api.err = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return; }
     api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
     api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
@@ -2108,7 +2121,6 @@ RcclApi* rccl_api()
         api.err = "RCCL: a symbol is missing from the loaded library";
         api.lib = nullptr;
     }
-    return &api;
 }
 
 // one all-reduce (sum, in place) of a device buffer over the ranks of a data-parallel step.  Native (azr_dp_init): ncclAllReduce on
@@ -2445,9 +2457,11 @@ static int train_impl(azr_engine* h, const void* rec265_host, size_t n, int epoc
 {
     if (!h->weights_set) { h->err = "azr_nn_train: no weights"; return AZR_E_STATE; }
     if (!rec265_host || epochs < 0 || batch_size < 2) { h->err = "azr_nn_train: bad arguments"; return AZR_E_INVALID_ARGUMENT; }
-    // no callback: the handle's own communicator (azr_dp_init) carries the sums.  (AZR_DP_LOOPBACK=1, a timing aid: a ONE-rank
-    // communicator stands in for `world` ranks — rank 0's share of the step with every collective in the stream, sums stay local.)
-    static const bool loopback = getenv("AZR_DP_LOOPBACK") && atoi(getenv("AZR_DP_LOOPBACK")) != 0;
+    // no callback: the handle's own communicator (azr_dp_init) carries the sums.  (Test hook AZR_DP_LOOPBACK=1 — libazr_hip_test.so only, a
+    // timing aid of tools/train_bench.py: a ONE-rank communicator stands in for `world` ranks — rank 0's share of the step with every
+    // collective in the stream, sums stay local, so the weights it leaves are NOT those of a real step.  The product library has no such
+    // switch: a communicator of another world size is refused.)
+    const bool loopback = hook_env_int("AZR_DP_LOOPBACK", 0) != 0;
     const bool native = dp_call && !ar && h->dp_comm && ((h->dp_world == world && h->dp_rank == rank) || (loopback && h->dp_world == 1 && rank == 0));
     if (world < 1 || rank < 0 || rank >= world || (world > 1 && !ar && !native) || batch_size % world != 0 || batch_size / world < 2) {
         h->err = "azr_nn_train_dp: need 0 <= rank < world, batch_size a multiple of world with >= 2 records per rank, and either an all-reduce "

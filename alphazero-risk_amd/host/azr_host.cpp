@@ -31,6 +31,24 @@ void mkdirs(const std::string& path)
 }
 }  // namespace
 
+// One host thread per GPU (the reference's structure: alphazero_trainer.cpp:48-57, game.cpp:277-312).  An exception thrown in a
+// thread body would end the process in std::terminate: it is caught there, every thread is joined, and the first failure is
+// raised in the caller's thread with the GPU it came from.
+void forEachGpu(int P, const char* what, const std::function<void(int)>& body)
+{
+    std::vector<std::string> failed(P);
+    std::vector<std::thread> threads;
+    for (int i = 0; i < P; i++)
+        threads.emplace_back([&, i]() {
+            try { body(i); }
+            catch (const std::exception& ex) { failed[i] = ex.what()[0] ? ex.what() : "unknown error"; }
+            catch (...) { failed[i] = "unknown error"; }
+        });
+    for (auto& t : threads) t.join();
+    for (int i = 0; i < P; i++)
+        if (!failed[i].empty()) throw std::runtime_error(std::string(what) + " on gpu " + std::to_string(i) + ": " + failed[i]);
+}
+
 void Settings::init(int argc, char* argv[])
 {
     // name, description (as the reference's help text), default — settings.h:91-137
@@ -72,6 +90,8 @@ void Settings::init(int argc, char* argv[])
         {"blocks", "[this build] residual blocks of the net (reference: compile-time BLOCKS)", std::to_string(BLOCKS), false},
         {"dtype", "[this build] net arithmetic bf16|f16|f32x|f32 (f32x = fp32-equivalent on the MFMA)", NET_DTYPE, false},
         {"seed", "[this build] base seed of the per-game RNG streams", std::to_string(BASE_SEED), false},
+        {"devices", "[this build] HIP device of every logical gpu, comma separated (default 0,1,..; \"0,0\" rehearses --gpus 2 on one card)", "", false},
+        {"pair-halves", "[this build] mirrored pairs: 1 = both games of a pair at the same time on two slots, 0 = one after the other on one slot", std::to_string(CONCURRENT_PAIR_HALVES), true},
         {"help", "Display help", "0", true},
     };
     std::map<std::string, std::string> val;
@@ -145,6 +165,17 @@ void Settings::init(int argc, char* argv[])
     BLOCKS = atoi(get("blocks").c_str());
     NET_DTYPE = get("dtype");
     BASE_SEED = (uint32_t)strtoul(get("seed").c_str(), nullptr, 10);
+    CONCURRENT_PAIR_HALVES = parse_bool(get("pair-halves"));
+    DEVICE_MAP.clear();
+    {
+        std::stringstream ss(get("devices"));
+        std::string tok;
+        while (std::getline(ss, tok, ',')) if (!tok.empty()) DEVICE_MAP.push_back(atoi(tok.c_str()));
+        if (!DEVICE_MAP.empty() && (int)DEVICE_MAP.size() != NUMBER_OF_GPUS) {
+            fprintf(stderr, "--devices names %d devices for --gpus %d\n", (int)DEVICE_MAP.size(), NUMBER_OF_GPUS);
+            exit(2);
+        }
+    }
     // `--lnt` and `--apbs` are parsed and never applied in the reference either
     mkdirs("log");
     std::ofstream out("log/settings.txt", std::ofstream::out);
@@ -374,7 +405,7 @@ std::shared_ptr<AlphaZeroNNGroup> AlphaZeroCluster::initPlayerGroup(const std::s
     auto grp = std::make_shared<AlphaZeroNNGroup>();
     grp->name = name;
     for (int gpu = 0; gpu < gpus; gpu++) {
-        auto eng = std::make_shared<Engine>(SETTINGS, gpu, SETTINGS.NUMBER_OF_CONCURENT_GAMES_PER_GPU);
+        auto eng = std::make_shared<Engine>(SETTINGS, SETTINGS.deviceOf(gpu), SETTINGS.NUMBER_OF_CONCURENT_GAMES_PER_GPU);
         grp->neuralNetworkIds.push_back(std::make_shared<AlphaZeroNNId>(eng, gpu));
     }
     groups.push_back(grp);
@@ -470,7 +501,6 @@ SelfPlayReport AlphaZeroTrainer::generateTrainData(std::shared_ptr<AlphaZeroNNGr
     printf("Generating training data current sample count %d\n", int(trainStorage.data.size()));
     std::vector<NNTrainDataStorage> storageGroup(P);
     std::vector<SelfPlayReport> rep(P);
-    std::vector<std::thread> threads;
     // GPU i's seed stream: base + i * 2^24 + (games this GPU has started in earlier iterations) — no game of any
     // (iteration, GPU) pair is ever replayed.  Shares, seeds and the stream positions are fixed HERE, by the parent, before
     // any thread exists: the threads only read their own copies.
@@ -482,44 +512,32 @@ SelfPlayReport AlphaZeroTrainer::generateTrainData(std::shared_ptr<AlphaZeroNNGr
         seeds[i] = SETTINGS.BASE_SEED + (uint32_t)i * (1u << 24) + (uint32_t)selfPlayStarted[i];
         selfPlayStarted[i] += shares[i];
     }
-    std::vector<std::string> failed(P);   // a thread's error text; raised after join() (a throw inside a std::thread terminates)
     auto t0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < P; i++) {
+    forEachGpu(P, "self-play", [&](int i) {  // one self-play thread per GPU (alphazero_trainer.cpp:48-57)
         const uint64_t share = shares[i];
         const uint32_t seed = seeds[i];
-        if (share == 0) continue;
-        threads.emplace_back([&, i, share, seed]() {  // one self-play thread per GPU (alphazero_trainer.cpp:48-57)
-          try {
-            Engine& e = *generate->getNN(i)->engine;
-            // exactly `share` games are started and every one is played to its end (Counter::hasNext over
-            // TRAIN_ITERATION_GAMES, alphazero_trainer.cpp:83)
-            e.check(azr_selfplay_start_games(e.h, seed, share), "selfplay_start_games");
-            azr_counters c{};
-            std::vector<uint8_t> buf((size_t)e.games * 512 * AZR_RECORD_BYTES);
-            while (c.games_finished + c.errors < share) {
-                e.check(azr_selfplay_run(e.h, 4 * (SETTINGS.MCTS_SIMULATIONS + 2)), "selfplay_run");
-                e.check(azr_selfplay_counters(e.h, &c), "counters");
-                if (c.records_dropped) throw std::runtime_error("self-play records were dropped (sample_capacity too small)");
-                for (size_t n = buf.size() / AZR_RECORD_BYTES; n == buf.size() / AZR_RECORD_BYTES;) {  // a partial drain keeps the rest
-                    e.check(azr_samples_drain(e.h, buf.data(), buf.size() / AZR_RECORD_BYTES, &n), "drain");
-                    storageGroup[i].appendPacked(buf.data(), n);
-                }
-                printf("\r[gpu %d] games %llu/%llu  decisions %llu  simulations %llu", i, (unsigned long long)c.games_finished,
-                       (unsigned long long)share, (unsigned long long)c.decisions, (unsigned long long)c.simulations);
-                fflush(stdout);
+        if (share == 0) return;
+        Engine& e = *generate->getNN(i)->engine;
+        // exactly `share` games are started and every one is played to its end (Counter::hasNext over
+        // TRAIN_ITERATION_GAMES, alphazero_trainer.cpp:83)
+        e.check(azr_selfplay_start_games(e.h, seed, share), "selfplay_start_games");
+        azr_counters c{};
+        std::vector<uint8_t> buf((size_t)e.games * 512 * AZR_RECORD_BYTES);
+        while (c.games_finished + c.errors < share) {
+            e.check(azr_selfplay_run(e.h, 4 * (SETTINGS.MCTS_SIMULATIONS + 2)), "selfplay_run");
+            e.check(azr_selfplay_counters(e.h, &c), "counters");
+            if (c.records_dropped) throw std::runtime_error("self-play records were dropped (sample_capacity too small)");
+            for (size_t n = buf.size() / AZR_RECORD_BYTES; n == buf.size() / AZR_RECORD_BYTES;) {  // a partial drain keeps the rest
+                e.check(azr_samples_drain(e.h, buf.data(), buf.size() / AZR_RECORD_BYTES, &n), "drain");
+                storageGroup[i].appendPacked(buf.data(), n);
             }
-            rep[i].games = c.games_finished; rep[i].decisions = c.decisions; rep[i].simulations = c.simulations;
-            rep[i].samples = storageGroup[i].data.size(); rep[i].errors = c.errors;
-          } catch (const std::exception& ex) {
-            failed[i] = ex.what()[0] ? ex.what() : "unknown error";
-          } catch (...) {
-            failed[i] = "unknown error";
-          }
-        });
-    }
-    for (auto& t : threads) t.join();
-    for (int i = 0; i < P; i++)
-        if (!failed[i].empty()) throw std::runtime_error("self-play on gpu " + std::to_string(i) + ": " + failed[i]);
+            printf("\r[gpu %d] games %llu/%llu  decisions %llu  simulations %llu", i, (unsigned long long)c.games_finished,
+                   (unsigned long long)share, (unsigned long long)c.decisions, (unsigned long long)c.simulations);
+            fflush(stdout);
+        }
+        rep[i].games = c.games_finished; rep[i].decisions = c.decisions; rep[i].simulations = c.simulations;
+        rep[i].samples = storageGroup[i].data.size(); rep[i].errors = c.errors;
+    });
     SelfPlayReport tot;
     tot.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const size_t before = trainStorage.data.size();
@@ -582,41 +600,39 @@ GameResults GameGroup::playGames(AlphaZeroPlayerGroup& pg1, AlphaZeroPlayerGroup
     printf("Playing games %d\n", games);
     std::vector<azr_game_results> res(P);
     std::vector<NNTrainDataStorage> st(P);
-    std::vector<std::thread> threads;
     const int pairs = games / 2;  // Counter::hasNext(2): whole pairs only
-    for (int i = 0; i < P; i++)
-        threads.emplace_back([&, i]() {
-            Engine& e = *pg1.nnGroup->getNN(i)->engine;
-            Engine& o = *pg2.nnGroup->getNN(i)->engine;
-            memset(&res[i], 0, sizeof res[i]);
-            const int share = 2 * (pairs / P + (i < pairs % P ? 1 : 0));
-            if (share == 0) return;
-            e.check(azr_arena_set_opponent_net(e.h, o.h), "arena_set_opponent_net");
-            e.check(azr_arena_collect_samples(e.h, tds ? 1 : 0), "arena_collect_samples");
-            e.check(azr_arena_start(e.h, AZR_PLAYER_ALPHAZERO, AZR_PLAYER_ALPHAZERO_B, share, 0, SETTINGS.MIRROR_GAMES,
-                                    SETTINGS.BASE_SEED + 7919u * arenaCallsBase + (uint32_t)i * (1u << 24)), "arena_start");
-            int fin = 0;
-            std::vector<uint8_t> buf;
-            while (!fin) {
-                e.check(azr_arena_run(e.h, 4 * (SETTINGS.MCTS_SIMULATIONS + 2), &fin), "arena_run");
-                e.check(azr_arena_results(e.h, &res[i]), "arena_results");
-                if (tds) {
-                    buf.resize((size_t)e.games * 512 * AZR_RECORD_BYTES);
-                    for (size_t n = buf.size() / AZR_RECORD_BYTES; n == buf.size() / AZR_RECORD_BYTES;) {
-                        e.check(azr_samples_drain(e.h, buf.data(), buf.size() / AZR_RECORD_BYTES, &n), "drain");
-                        st[i].appendPacked(buf.data(), n);
-                    }
-                }
-                if (i == 0) {
-                    printf("\r%d/%d [Draw/P1,P2]: %d, %d/%d, %d/%d", res[i].count, share, res[i].draw, res[i].win[0], res[i].win_and_started[0],
-                           res[i].win[1], res[i].win_and_started[1]);
-                    fflush(stdout);
+    const int mirror = SETTINGS.arenaMirrorMode();
+    forEachGpu(P, "compare games", [&](int i) {
+        Engine& e = *pg1.nnGroup->getNN(i)->engine;
+        Engine& o = *pg2.nnGroup->getNN(i)->engine;
+        memset(&res[i], 0, sizeof res[i]);
+        const int share = 2 * (pairs / P + (i < pairs % P ? 1 : 0));
+        if (share == 0) return;
+        e.check(azr_arena_set_opponent_net(e.h, o.h), "arena_set_opponent_net");
+        e.check(azr_arena_collect_samples(e.h, tds ? 1 : 0), "arena_collect_samples");
+        e.check(azr_arena_start(e.h, AZR_PLAYER_ALPHAZERO, AZR_PLAYER_ALPHAZERO_B, share, 0, mirror,
+                                SETTINGS.BASE_SEED + 7919u * arenaCallsBase + (uint32_t)i * (1u << 24)), "arena_start");
+        int fin = 0;
+        std::vector<uint8_t> buf;
+        while (!fin) {
+            e.check(azr_arena_run(e.h, 4 * (SETTINGS.MCTS_SIMULATIONS + 2), &fin), "arena_run");
+            e.check(azr_arena_results(e.h, &res[i]), "arena_results");
+            if (tds) {
+                buf.resize((size_t)e.games * 512 * AZR_RECORD_BYTES);
+                for (size_t n = buf.size() / AZR_RECORD_BYTES; n == buf.size() / AZR_RECORD_BYTES;) {
+                    e.check(azr_samples_drain(e.h, buf.data(), buf.size() / AZR_RECORD_BYTES, &n), "drain");
+                    st[i].appendPacked(buf.data(), n);
                 }
             }
-            e.check(azr_arena_collect_samples(e.h, 0), "arena_collect_samples");
-            e.check(azr_arena_set_opponent_net(e.h, nullptr), "arena_set_opponent_net");
-        });
-    for (auto& t : threads) t.join();
+            if (i == 0) {
+                printf("\r%d/%d [Draw/P1,P2]: %d, %d/%d, %d/%d", res[i].count, share, res[i].draw, res[i].win[0], res[i].win_and_started[0],
+                       res[i].win[1], res[i].win_and_started[1]);
+                fflush(stdout);
+            }
+        }
+        e.check(azr_arena_collect_samples(e.h, 0), "arena_collect_samples");
+        e.check(azr_arena_set_opponent_net(e.h, nullptr), "arena_set_opponent_net");
+    });
     printf("\n");
     GameResults all;
     for (auto& r : res) {
@@ -633,21 +649,19 @@ GameResults GameGroup::playGames(AlphaZeroPlayerGroup& pg1, int otherKind, int g
     const int P = (int)pg1.nnGroup->size();
     printf("Playing games %d\n", games);
     std::vector<azr_game_results> res(P);
-    std::vector<std::thread> threads;
     const int pairs = games / 2;
-    for (int i = 0; i < P; i++)
-        threads.emplace_back([&, i]() {
-            Engine& e = *pg1.nnGroup->getNN(i)->engine;
-            const int share = 2 * (pairs / P + (i < pairs % P ? 1 : 0));
-            memset(&res[i], 0, sizeof res[i]);
-            if (share == 0) return;
-            e.check(azr_arena_start(e.h, AZR_PLAYER_ALPHAZERO, otherKind, share, 0, SETTINGS.MIRROR_GAMES,
-                                    SETTINGS.BASE_SEED + 104729u * arenaCallsBase + (uint32_t)i * (1u << 24)), "arena_start");
-            int fin = 0;
-            while (!fin) e.check(azr_arena_run(e.h, 4 * (SETTINGS.MCTS_SIMULATIONS + 2), &fin), "arena_run");
-            e.check(azr_arena_results(e.h, &res[i]), "arena_results");
-        });
-    for (auto& t : threads) t.join();
+    const int mirror = SETTINGS.arenaMirrorMode();
+    forEachGpu(P, "benchmark games", [&](int i) {
+        Engine& e = *pg1.nnGroup->getNN(i)->engine;
+        const int share = 2 * (pairs / P + (i < pairs % P ? 1 : 0));
+        memset(&res[i], 0, sizeof res[i]);
+        if (share == 0) return;
+        e.check(azr_arena_start(e.h, AZR_PLAYER_ALPHAZERO, otherKind, share, 0, mirror,
+                                SETTINGS.BASE_SEED + 104729u * arenaCallsBase + (uint32_t)i * (1u << 24)), "arena_start");
+        int fin = 0;
+        while (!fin) e.check(azr_arena_run(e.h, 4 * (SETTINGS.MCTS_SIMULATIONS + 2), &fin), "arena_run");
+        e.check(azr_arena_results(e.h, &res[i]), "arena_results");
+    });
     GameResults all;
     for (auto& r : res) {
         all.count += r.count; all.draw += r.draw;

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -65,6 +66,11 @@ public:
     int BLOCKS = 20;              // CMakeLists.txt:15 `set(BLOCKS 20)` is compile-time in the reference
     std::string NET_DTYPE = "bf16";
     uint32_t BASE_SEED = 20260001;
+    std::vector<int> DEVICE_MAP;         // --devices: HIP device of logical gpu i (empty = i); "0,0" rehearses --gpus 2 on one card
+    bool CONCURRENT_PAIR_HALVES = true;  // --pair-halves: the two games of a mirrored pair on two slots at the same time (AZR_MIRROR_CONCURRENT)
+
+    int deviceOf(int gpu) const { return DEVICE_MAP.empty() ? gpu : DEVICE_MAP.at(gpu); }
+    int arenaMirrorMode() const { return !MIRROR_GAMES ? AZR_MIRROR_OFF : CONCURRENT_PAIR_HALVES ? AZR_MIRROR_CONCURRENT : AZR_MIRROR_SEQUENTIAL; }
 
     int getNumberOfPlayers() const { return NUMBER_OF_GPUS * NUMBER_OF_CONCURENT_GAMES_PER_GPU; }
     void init(int argc, char* argv[]);   // parses every flag of SURVEY App-G; exits on -h/--help
@@ -72,6 +78,9 @@ public:
     std::string describe() const;
 };
 extern Settings SETTINGS;
+
+// one host thread per GPU; a failure inside a thread is raised in the caller after every thread has been joined
+void forEachGpu(int P, const char* what, const std::function<void(int)>& body);
 
 // ------------------------------------------------------------------------------------------------------------------
 // byte images with the reference's layouts

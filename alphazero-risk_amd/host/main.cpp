@@ -1,7 +1,7 @@
 // AlphaZero_Risk_hip — CLI of the MI355X-native build; flags and modes as src/alphazero_risk.cpp:160-199 /
 // src/settings.h:91-137 (`-m learn` = `-m train`).
 #include <cstdio>
-#include <thread>
+#include <cstring>
 
 #include "azr_host.hpp"
 
@@ -54,26 +54,26 @@ static void executePlay()
     // one host thread per GPU, the game quota split over the GPUs (the reference shares one Counter)
     const int P = (int)group->size();
     std::vector<azr_game_results> res(P);
-    std::vector<std::thread> threads;
     printf("Playing games %d\n", SETTINGS.COMPARE_GAMES);
-    for (int i = 0; i < P; i++)
-        threads.emplace_back([&, i]() {
-            Engine& e = *group->getNN(i)->engine;
-            const int share = SETTINGS.COMPARE_GAMES / P + (i < SETTINGS.COMPARE_GAMES % P ? 1 : 0);
-            e.check(azr_arena_start(e.h, k1, k2, share, 0, SETTINGS.MIRROR_GAMES, SETTINGS.BASE_SEED + (uint32_t)i * (1u << 24)),
-                    "arena_start");
-            int fin = 0;
-            while (!fin) {
-                e.check(azr_arena_run(e.h, 4 * (SETTINGS.MCTS_SIMULATIONS + 2), &fin), "arena_run");
-                e.check(azr_arena_results(e.h, &res[i]), "arena_results");
-                if (i == 0) {
-                    printf("\r%d/%d [Draw/P1,P2]: %d, %d/%d, %d/%d", res[i].count, share, res[i].draw, res[i].win[0],
-                           res[i].win_and_started[0], res[i].win[1], res[i].win_and_started[1]);
-                    fflush(stdout);
-                }
+    const int pairs = SETTINGS.COMPARE_GAMES / 2;   // Counter::hasNext(2): whole pairs only (game.cpp:14-26)
+    forEachGpu(P, "play", [&](int i) {
+        Engine& e = *group->getNN(i)->engine;
+        memset(&res[i], 0, sizeof res[i]);
+        const int share = 2 * (pairs / P + (i < pairs % P ? 1 : 0));
+        if (share == 0) return;
+        e.check(azr_arena_start(e.h, k1, k2, share, 0, SETTINGS.arenaMirrorMode(), SETTINGS.BASE_SEED + (uint32_t)i * (1u << 24)),
+                "arena_start");
+        int fin = 0;
+        while (!fin) {
+            e.check(azr_arena_run(e.h, 4 * (SETTINGS.MCTS_SIMULATIONS + 2), &fin), "arena_run");
+            e.check(azr_arena_results(e.h, &res[i]), "arena_results");
+            if (i == 0) {
+                printf("\r%d/%d [Draw/P1,P2]: %d, %d/%d, %d/%d", res[i].count, share, res[i].draw, res[i].win[0],
+                       res[i].win_and_started[0], res[i].win[1], res[i].win_and_started[1]);
+                fflush(stdout);
             }
-        });
-    for (auto& t : threads) t.join();
+        }
+    });
     azr_game_results gr{};
     for (auto& r : res) {
         gr.count += r.count; gr.draw += r.draw;

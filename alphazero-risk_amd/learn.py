@@ -31,7 +31,7 @@ P = importlib.import_module("alphazero-risk_amd")
 shard_mod = importlib.import_module("alphazero-risk_amd.shard")
 
 
-def arena_device(eng_new, eng_old, games, mirror=True, base_seed=1, collect=False):
+def arena_device(eng_new, eng_old, games, mirror=P.MIRROR_CONCURRENT, base_seed=1, collect=False):
     """the same arena resident on the device (azr_arena_* with AZR_PLAYER_ALPHAZERO_B = eng_old's network): every slot
     advances on its own, each network is evaluated on its own player's leaves; optionally returns the (s, pi, z)
     records both players produced (INCLUDE_COMPARE_GAMES_TRAIN_SAMPLES)"""
@@ -117,6 +117,7 @@ def load_training_samples(path):
 
 
 def run_arena(eng, p1, p2, games, mirror, seed):
+    """GameGroup::playGames of an AlphaZero player group against ScriptPlayer / RandomPlayer (the benchmark games)"""
     eng.arena_start(p1, p2, games, 0, mirror, seed)
     while not eng.arena_run(4 * (eng.settings.mcts_simulations + 2)):
         pass
@@ -131,11 +132,42 @@ def reduce_results(gr, dist, dev):
     return dict(count=r["count"], draw=r["draw"], win=[r["w0"], r["w1"]], win_and_started=[r["s0"], r["s1"]])
 
 
+class Deadline:
+    """watchdog of a multi-rank run: a collective whose partner died never returns (an in-stream ncclAllReduce blocks the next
+    stream synchronisation, a gloo / RCCL call of torch blocks in the call), so a timer thread ends THIS process with a message
+    and exit code 124 when a phase overruns; the launcher (torchrun, bench.py's parent) then ends the other ranks.
+    arm(what) starts the clock of the next phase (and stops the previous one's), disarm() stops it."""
+
+    def __init__(self, seconds, rank):
+        self.seconds, self.rank, self.timer = seconds, rank, None
+
+    def arm(self, what):
+        self.disarm()
+        if self.seconds and self.seconds > 0:
+            import threading
+            self.timer = threading.Timer(self.seconds, self._expired, args=(what,))
+            self.timer.daemon = True
+            self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def _expired(self, what):
+        sys.stderr.write(f"learn.py: rank {self.rank} spent more than {self.seconds:.0f} s in '{what}': a rank is missing from a "
+                         "collective; ending this process (exit code 124)\n")
+        sys.stderr.flush()
+        os._exit(124)
+
+
 def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
     os.makedirs("log", exist_ok=True)
     os.makedirs("checkpoints", exist_ok=True)
     dtype = {"bf16": P.NET_BF16, "f16": P.NET_F16, "f32x": P.NET_F32X, "f32": P.NET_F32}[a.dtype]
     t = getattr(a, "t", 2)
+    # MIRROR_GAMES (settings.h:52): mirrored pairs; --pair-halves 1 plays a pair's two games at the same time on two slots
+    mirror = P.MIRROR_CONCURRENT if getattr(a, "pair_halves", 1) and a.gpu_games >= 2 else P.MIRROR_SEQUENTIAL
     if rank != 0:
         log = lambda *_: None   # noqa: E731  (rank 0 reports)
     gen = P.Engine(a.gpu_games, blocks=a.blocks, sims=a.mcts, dtype=dtype, device=a.device, threads=t)
@@ -159,8 +191,10 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
     bench_log = open(sink or "log/azr-benchmark-log.txt", "a")
     nn_log = open(sink or "log/azr-nn-training-log.txt", "a")
     summary = []
+    wd = Deadline(getattr(a, "phase_deadline", 0) if dist is not None else 0, rank)
     for it in range(a.ti):
         log(f"Train iteration {it}")
+        wd.arm("self-play and record exchange")
         # ---- generateTrainData (alphazero_trainer.cpp:36-78)
         t0 = time.time()
         share = shard_mod.split_count(a.tg, world, rank)   # one self-play shard per GPU (alphazero_trainer.cpp:41-57)
@@ -189,15 +223,18 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
         records = np.concatenate([records, new_recs])
         records, old_game_index = trim_old_examples(records, old_game_index, a.s, 16384 * a.bs)
         # ---- trainGroup->train (alphazero_gpu_cluster.cpp:221-231)
+        wd.arm("training and weight hand-over")
         t0 = time.time()
         hist = []
-        # --dp -1 (default): data-parallel from 4 ranks on.  A rank's share of the reference's BATCH_SIZE 512 is then <= 128 records,
-        # which the small-batch conv kernels (t_conv_q: one board x 64 channels per block, 8-board weight-gradient slices) spread over
-        # the whole GPU: rank 0's 64-record share of an 8-rank step takes 4.2 ms of kernels against 11.1 ms for all 512 records on one
-        # GPU (tools/train_bench.py --dp-world 8), plus 2B + 6 small in-stream all-reduces and one of 95 MB.  With 2 ranks the 256-record
-        # share runs the large-batch kernels at ~6 ms and the all-reduces eat the rest: rank 0 trains, as the reference does.
-        dp_flag = getattr(a, "dp", -1)
-        dp = dist is not None and a.bs % world == 0 and a.bs // world >= 2 and (dp_flag == 1 or (dp_flag < 0 and world >= 4 and a.bs // world >= 16 and (a.bs // world) % 16 == 0))
+        # --dp 0 (default): rank 0 trains and the others receive its weights, the reference's AlphaZeroNNGroup::train.  --dp 1: data-parallel
+        # optimiser step.  A rank's share of the reference's BATCH_SIZE 512 on 8 ranks is 64 records, which the small-batch conv kernels
+        # (t_conv_q: one board x 64 channels per block, 8-board weight-gradient slices) spread over the whole GPU: 4.2 ms of kernels against
+        # 11.1 ms for all 512 records on one GPU — measured on ONE GPU with a one-rank stand-in for the collectives (tools/train_bench.py
+        # --dp-world 8); what 2B + 6 latency-bound all-reduces and one of 95 MB cost over xGMI has not been measured, and equality of the
+        # ranks' weights has been shown over gloo and in-process (tests/test_gpu_train_dp.py), not over RCCL with more than one rank:
+        # opt-in until a run on a multi-GPU node is on record.
+        dp_flag = getattr(a, "dp", 0)
+        dp = dist is not None and dp_flag == 1 and a.bs % world == 0 and a.bs // world >= 2
         if dp:
             # data-parallel optimiser step: every rank takes 1/world of each minibatch (same shuffle stream everywhere);
             # batch statistics, losses and the gradient vector are all-reduced (RCCL over xGMI), every rank takes the
@@ -232,13 +269,14 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
         if hist:
             log(f"Loss Policy / Value: {hist[-1][0]:f} / {hist[-1][1]:f}   [{steps} steps, {1e3 * (time.time() - t0) / max(steps, 1):.1f} ms/step]")
         # ---- updateIfImprovement (alphazero_trainer.cpp:134-190)
+        wd.arm("compare and benchmark games")
         improved = True
         gr = None
         t_arena = time.time()
         if a.cg > 0:
             share = 2 * shard_mod.split_count(a.cg // 2, world, rank)
             aseed = shard_mod.rank_base_seed(a.seed + 7919 * (it + 1), rank)
-            gr, arecs = arena_device(new, gen, share, True, aseed, collect=bool(getattr(a, "include_compare_samples", 1)))
+            gr, arecs = arena_device(new, gen, share, mirror, aseed, collect=bool(getattr(a, "include_compare_samples", 1)))
             if dist is not None:
                 gr = reduce_results(gr, dist, cdev)
                 import torch
@@ -255,9 +293,9 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
                 new.save(best); new.save(f"checkpoints/checkpoint-iter-{it}.bin")
             gen.set_weights(new.get_weights())   # generateGroup->loadCheckpoint(best): every rank already holds them
             t_bench = time.time()
-            r = run_arena(gen, P.PLAYER_ALPHAZERO, P.PLAYER_RANDOM, 2 * shard_mod.split_count(5, world, rank), True,
+            r = run_arena(gen, P.PLAYER_ALPHAZERO, P.PLAYER_RANDOM, 2 * shard_mod.split_count(5, world, rank), mirror,
                           shard_mod.rank_base_seed(a.seed + 11 + 104729 * (it + 1), rank))
-            s = run_arena(gen, P.PLAYER_ALPHAZERO, P.PLAYER_SCRIPT, 2 * shard_mod.split_count(50, world, rank), True,
+            s = run_arena(gen, P.PLAYER_ALPHAZERO, P.PLAYER_SCRIPT, 2 * shard_mod.split_count(50, world, rank), mirror,
                           shard_mod.rank_base_seed(a.seed + 13 + 15485863 * (it + 1), rank))
             if dist is not None:
                 r, s = reduce_results(r, dist, cdev), reduce_results(s, dist, cdev)
@@ -267,6 +305,7 @@ def learn(a, log=print, dist=None, rank=0, world=1, cdev="cpu"):
         else:
             log("Model did not improve\nModel reverted back old")
             new.load(latest)
+        wd.disarm()
         summary.append(dict(iteration=it, samples=len(records), losses=hist, arena=gr, improved=improved))
     # saveTrainingSamples (reference writer layout: 8-byte count + 265-byte records)
     if rank == 0:
@@ -293,9 +332,15 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32x", "f32"])
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--include-compare-samples", type=int, default=1)   # INCLUDE_COMPARE_GAMES_TRAIN_SAMPLES
-    ap.add_argument("--dp", type=int, default=-1,
-                    help="multi-rank runs: 1 = data-parallel optimiser step over all ranks, 0 = rank 0 trains and broadcasts "
-                         "(the reference's AlphaZeroNNGroup::train), -1 (default) = data-parallel from 4 ranks on")
+    ap.add_argument("--pair-halves", type=int, default=1,
+                    help="mirrored arena pairs: 1 = both games of a pair at the same time on two slots (AZR_MIRROR_CONCURRENT), "
+                         "0 = one after the other on one slot (the reference's thread-per-pair form)")
+    ap.add_argument("--dp", type=int, default=0,
+                    help="multi-rank runs: 0 (default) = rank 0 trains and broadcasts (the reference's AlphaZeroNNGroup::train), "
+                         "1 = data-parallel optimiser step over all ranks (opt-in: not yet measured on a multi-GPU node)")
+    ap.add_argument("--phase-deadline", type=float, default=float(os.environ.get("AZR_LEARN_DEADLINE_S", "3600")),
+                    help="multi-rank runs: seconds a rank may spend in one phase of an iteration (self-play + exchange, training, arena) before "
+                         "it ends the process — a rank that died leaves the others waiting in a collective for ever otherwise")
     ap.add_argument("--dp-callback", type=int, default=0,
                     help="1 = the data-parallel step's sums go through torch.distributed (one host hand-over each) instead of the engine's own "
                          "in-stream RCCL communicator")

@@ -220,21 +220,30 @@ def optimiser_step_leg(pkg, blocks, bs=512, batches=10, epochs=12):
 
 def arena_leg(pkg, blocks, games=100, slots=128, sims=100, threads=2):
     """the learn loop's new-vs-old comparison (GameGroup::playGames with two AlphaZero players and two networks, game.cpp:277-312;
-    alphazero_trainer.cpp:147-152) on the device: wall time of `games` mirrored games"""
+    alphazero_trainer.cpp:147-152) on the device: wall time of `games` mirrored games — the two games of a pair at the same time on
+    two slots (AZR_MIRROR_CONCURRENT, the learn loops' default), and the reference's thread-per-pair form (one after the other on one
+    slot) beside it"""
     new = pkg.Engine(slots, blocks=blocks, sims=sims, dtype=pkg.NET_BF16, threads=threads)
     old = pkg.Engine(slots, blocks=blocks, sims=sims, dtype=pkg.NET_BF16, threads=threads)
     new.init_random(1)
     old.init_random(2)
     new.arena_set_opponent(old)
-    new.arena_start(pkg.PLAYER_ALPHAZERO, pkg.PLAYER_ALPHAZERO_B, games, 0, True, 20260001)
-    t0 = time.perf_counter()
-    while not new.arena_run(256):
-        pass
-    dt = time.perf_counter() - t0
-    r = new.arena_results()
+    out = {}
+    for name, mode in (("concurrent", pkg.MIRROR_CONCURRENT), ("sequential", pkg.MIRROR_SEQUENTIAL)):
+        new.arena_start(pkg.PLAYER_ALPHAZERO, pkg.PLAYER_ALPHAZERO_B, games, 0, mode, 20260001)
+        t0 = time.perf_counter()
+        while not new.arena_run(256):
+            pass
+        out[name] = (time.perf_counter() - t0, new.arena_results())
+    fb = new.counters()["tower_fallbacks"]
+    new.arena_set_opponent(None)
     new.close(); old.close()
-    return {"wall_s": dt, "games": games, "slots": slots, "sims_per_move": sims, "mcts_threads": threads, "blocks": blocks, "results": r,
-            "what": "two-net arena: 50 mirrored pairs, each pair's two games one after the other on one slot; launches of <= 128 leaves (k_tower_sc)"}
+    return {"wall_s": out["concurrent"][0], "games": games, "slots": slots, "sims_per_move": sims, "mcts_threads": threads, "blocks": blocks,
+            "results": out["concurrent"][1], "sequential_wall_s": out["sequential"][0], "sequential_results": out["sequential"][1],
+            "tower_fallbacks": fb,
+            "what": "two-net arena, 50 mirrored pairs: `wall_s` with a pair's two games at the same time on two slots (100 slots busy), "
+                    "`sequential_wall_s` with each pair's games one after the other on one slot (the reference's thread-per-pair form); "
+                    "launches of <= 128 leaves (k_tower_sc)"}
 
 
 def run_config(ctx, games, sims, threads, steps, warmup, tail, dtype=None, midgame=False):

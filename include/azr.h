@@ -200,6 +200,11 @@ typedef struct azr_counters {
     uint64_t errors;        /* games stopped on a rules error (should be 0) */
     uint64_t records_dropped; /* records lost because a game outgrew sample_capacity or the ring was full (should be 0;
                                  `samples` counts them too) */
+    uint64_t tower_fallbacks; /* net launches of <= 128 boards (split-channel tower, 4 co-resident workgroups per board pair) in which a
+                                 workgroup waited for its partners longer than the spin limit — the GPU was shared with something that kept
+                                 them from running — and which the one-board-per-workgroup kernel queued behind them recomputed, in
+                                 stream order: results are unaffected, the count says how often it happened since the handle exists
+                                 (normally 0) */
 } azr_counters;
 int azr_selfplay_counters(azr_engine* h, azr_counters* out);
 /* finished games' records, z filled (NNTrainDataStorage::updateValues, alphazero_nn_data.cpp:51-65).  Copies the first
@@ -224,7 +229,18 @@ typedef struct azr_game_results {   /* GameResults (game/game.h:17-29) */
     int32_t count, draw;
     int32_t win[2], win_and_started[2];
 } azr_game_results;
-/* games = Counter::count; games_per_slot_cap > 0 additionally limits every slot (deterministic splits for tests) */
+/* mirror_games (SETTINGS.MIRROR_GAMES, game.cpp:170-191):
+ *   AZR_MIRROR_OFF         every game a fresh deal
+ *   AZR_MIRROR_SEQUENTIAL  the reference's thread-per-pair form: a slot deals, plays the game, then plays the same deal with the
+ *                          players inverted (State::invertPlayers, state.cpp:493-516); slot g draws everything — deals and dice of
+ *                          all its games — from ONE minstd_rand0 stream seeded base_seed + g (the reference's global engine)
+ *   AZR_MIRROR_CONCURRENT  the two games of a pair at the same time on the slots 2j and 2j + 1 (nothing in Game orders them, only
+ *                          the shared initial deal does).  Pair p = j + k (G/2) is the k-th pair of slot pair j; both halves deal from
+ *                          minstd_rand0(base_seed + p); half 0 (player 0 starts) goes on with that stream for its dice, half 1
+ *                          (invertPlayers of the same deal, player 1 starts) draws its dice from minstd_rand0(base_seed + p + 2^30).
+ *                          Pairs are assigned statically (p < games / 2), so a run is a function of its arguments alone; G even.
+ * games = Counter::count; games_per_slot_cap > 0 additionally limits every slot (deterministic splits for tests) */
+enum { AZR_MIRROR_OFF = 0, AZR_MIRROR_SEQUENTIAL = 1, AZR_MIRROR_CONCURRENT = 2 };
 int azr_arena_start(azr_engine* h, int player1, int player2, int games, int games_per_slot_cap, int mirror_games,
                     uint32_t base_seed);
 int azr_arena_run(azr_engine* h, int passes, int* finished_out);

@@ -1887,6 +1887,73 @@ int orc_play_games(const orc_settings* cfg, int kind0, int kind1, int games, int
                            NULL, 0, NULL, NULL);
 }
 
+/* Game::gameLoop + the bookkeeping after it (game.cpp:101-168) for ONE game that starts in state *s: both players'
+ * newGame, turns until the game ends, updateValues on the records logged during the game, GameResults::addGame. */
+typedef struct {
+    const orc_settings* cfg;
+    int kind[2];
+    orc_script sp[2];
+    orc_mcts* mc[2];
+    orc_eval_fn eval, eval_b;
+    void *ctx, *ctx_b;
+    orc_reclog log;
+} orc_table;
+
+static int play_out(orc_table* t, orc_state* s, orc_rng* r, int player_start, int gi, orc_results* res, int8_t* status_out,
+                    uint8_t* finals160, uint16_t* rounds_out, int* rec_game_end)
+{
+    const orc_settings* cfg = t->cfg;
+    int rc = ORC_OK;
+    for (int p = 0; p < 2; p++)
+        if (t->mc[p]) orc_mcts_clear(t->mc[p]); /* AlphaZeroPlayer::newGame */
+    int gs = ORC_NOT_ENDED;
+    while (gs == ORC_NOT_ENDED && rc == ORC_OK) { /* Game::gameLoop / playTurn (game.cpp:101-133) */
+        int cur = s->cur;
+        int setup = s->phase == ORC_SETUP;
+        if (t->kind[cur] == 1) rc = orc_script_take_turn(&t->sp[cur], s, r, cfg);
+        else if (t->kind[cur] == 2) rc = orc_random_take_turn(s, cur, r, cfg);
+        else if (t->kind[cur] == 3) rc = az_take_turn(t->mc[cur], s, cur, r, cfg, t->eval_b, t->ctx_b, &t->log);
+        else rc = az_take_turn(t->mc[cur], s, cur, r, cfg, t->eval, t->ctx, &t->log);
+        if (rc) break;
+        gs = setup ? ORC_NOT_ENDED : orc_game_status(s, cfg);
+        if (cur == s->cur && gs == ORC_NOT_ENDED) { rc = ORC_LOGIC_ERROR; break; } /* "Turn was not incremented" */
+    }
+    if (rc) return rc;
+    for (int i = t->log.game_start; i < t->log.n; i++) { /* updateValues (alphazero_nn_data.cpp:51-65) */
+        float z = gs == ORC_DRAW ? 0.0f : ((int)t->log.rec[(size_t)i * 265] == gs ? 1.0f : -1.0f);
+        memcpy(t->log.rec + (size_t)i * 265 + 89, &z, 4);
+    }
+    t->log.game_start = t->log.n;
+    if (rec_game_end) rec_game_end[gi] = t->log.n;
+    res->count++;
+    if (gs == ORC_DRAW) res->draw++;
+    for (int p = 0; p < 2; p++)
+        if (gs == p) { res->win[p]++; if (player_start == p) res->win_started[p]++; }
+    if (status_out) status_out[gi] = (int8_t)gs;
+    if (finals160) orc_state_pack(s, finals160 + (size_t)gi * 160);
+    if (rounds_out) rounds_out[gi] = s->round;
+    return ORC_OK;
+}
+
+static void table_open(orc_table* t, const orc_settings* cfg, int kind0, int kind1, orc_eval_fn eval, void* ctx, orc_eval_fn eval_b,
+                       void* ctx_b, uint8_t* rec265, int rec_cap)
+{
+    t->cfg = cfg;
+    t->kind[0] = kind0; t->kind[1] = kind1;
+    t->eval = eval; t->ctx = ctx; t->eval_b = eval_b; t->ctx_b = ctx_b;
+    t->log.rec = rec265; t->log.cap = rec_cap; t->log.n = 0; t->log.game_start = 0;
+    for (int p = 0; p < 2; p++) {
+        orc_script_init(&t->sp[p]);
+        t->mc[p] = (t->kind[p] == 0 || t->kind[p] == 3) ? orc_mcts_create(cfg) : NULL;
+    }
+}
+
+static void table_close(orc_table* t)
+{
+    for (int p = 0; p < 2; p++)
+        if (t->mc[p]) orc_mcts_destroy(t->mc[p]);
+}
+
 /* the same with kind 3 = an AlphaZero player on a second network (eval_b) — GameGroup::playGames(trainAZPG,
  * generateAZPG, ...) of the trainer — and optionally the 265-byte (s, pi, z) records of the AlphaZero decisions, game
  * by game in decision order, z filled in when the game ends (NNTrainDataStorage::updateValues) */
@@ -1894,16 +1961,10 @@ int orc_play_games2(const orc_settings* cfg, int kind0, int kind1, int games, in
                     orc_eval_fn eval, void* ctx, orc_eval_fn eval_b, void* ctx_b, orc_results* res, int8_t* status_out,
                     uint8_t* finals160, uint16_t* rounds_out, uint8_t* rec265, int rec_cap, int* rec_n, int* rec_game_end)
 {
-    orc_reclog log = {rec265, rec_cap, 0, 0};
+    orc_table t;
+    table_open(&t, cfg, kind0, kind1, eval, ctx, eval_b, ctx_b, rec265, rec_cap);
     orc_rng r;
     orc_rng_seed(&r, seed);
-    orc_script sp[2];
-    orc_mcts* mc[2] = {NULL, NULL};
-    const int kind[2] = {kind0, kind1};
-    for (int p = 0; p < 2; p++) {
-        orc_script_init(&sp[p]);
-        if (kind[p] == 0 || kind[p] == 3) mc[p] = orc_mcts_create(cfg);
-    }
     memset(res, 0, sizeof *res);
     orc_state s, prev_start;
     orc_state_blank(&prev_start);
@@ -1918,39 +1979,45 @@ int orc_play_games2(const orc_settings* cfg, int kind0, int kind1, int games, in
             s.cur = (int8_t)player_start;
             prev_start = s;
         }
-        for (int p = 0; p < 2; p++)
-            if (mc[p]) orc_mcts_clear(mc[p]); /* AlphaZeroPlayer::newGame */
-        int gs = ORC_NOT_ENDED;
-        while (gs == ORC_NOT_ENDED && rc == ORC_OK) { /* Game::gameLoop / playTurn (game.cpp:101-133) */
-            int cur = s.cur;
-            int setup = s.phase == ORC_SETUP;
-            if (kind[cur] == 1) rc = orc_script_take_turn(&sp[cur], &s, &r, cfg);
-            else if (kind[cur] == 2) rc = orc_random_take_turn(&s, cur, &r, cfg);
-            else if (kind[cur] == 3) rc = az_take_turn(mc[cur], &s, cur, &r, cfg, eval_b, ctx_b, &log);
-            else rc = az_take_turn(mc[cur], &s, cur, &r, cfg, eval, ctx, &log);
-            if (rc) break;
-            gs = setup ? ORC_NOT_ENDED : orc_game_status(&s, cfg);
-            if (cur == s.cur && gs == ORC_NOT_ENDED) { rc = ORC_LOGIC_ERROR; break; } /* "Turn was not incremented" */
-        }
-        if (rc) break;
-        for (int i = log.game_start; i < log.n; i++) { /* updateValues (alphazero_nn_data.cpp:51-65) */
-            float z = gs == ORC_DRAW ? 0.0f : ((int)log.rec[(size_t)i * 265] == gs ? 1.0f : -1.0f);
-            memcpy(log.rec + (size_t)i * 265 + 89, &z, 4);
-        }
-        log.game_start = log.n;
-        if (rec_game_end) rec_game_end[gi] = log.n;
-        res->count++;
-        if (gs == ORC_DRAW) res->draw++;
-        for (int p = 0; p < 2; p++)
-            if (gs == p) { res->win[p]++; if (player_start == p) res->win_started[p]++; }
-        if (status_out) status_out[gi] = (int8_t)gs;
-        if (finals160) orc_state_pack(&s, finals160 + (size_t)gi * 160);
-        if (rounds_out) rounds_out[gi] = s.round;
+        rc = play_out(&t, &s, &r, player_start, gi, res, status_out, finals160, rounds_out, rec_game_end);
         player_start = (player_start + 1) % 2;
     }
-    for (int p = 0; p < 2; p++)
-        if (mc[p]) orc_mcts_destroy(mc[p]);
+    table_close(&t);
     res->rng_state = r.x;
-    if (rec_n) *rec_n = log.n;
+    if (rec_n) *rec_n = t.log.n;
+    return rc;
+}
+
+/* One SLOT of the concurrent-halves form of a mirrored arena (include/azr.h, AZR_MIRROR_CONCURRENT): the two games of a pair are
+ * played at the same time by two tables — nothing in Game orders them (game.cpp:238-254), they only share the deal
+ * (game.cpp:170-191).  This slot plays half `half` of the pairs pair_seed0, pair_seed0 + pair_stride, ...: the deal of pair seed q
+ * comes from minstd_rand0(q); half 0 (player 0 starts) goes on with that stream, half 1 plays invertPlayers of the deal with
+ * player 1 starting and draws from minstd_rand0(q + 2^30).  Players (and a ScriptPlayer's memory) persist over the slot's games
+ * as they do over a reference thread's. */
+int orc_play_half_games(const orc_settings* cfg, int kind0, int kind1, int games, int half, uint32_t pair_seed0, uint32_t pair_stride,
+                        orc_eval_fn eval, void* ctx, orc_eval_fn eval_b, void* ctx_b, orc_results* res, int8_t* status_out,
+                        uint8_t* finals160, uint16_t* rounds_out, uint8_t* rec265, int rec_cap, int* rec_n, int* rec_game_end)
+{
+    orc_table t;
+    table_open(&t, cfg, kind0, kind1, eval, ctx, eval_b, ctx_b, rec265, rec_cap);
+    memset(res, 0, sizeof *res);
+    orc_rng r;
+    r.x = 0;
+    int rc = ORC_OK;
+    for (int gi = 0; gi < games && rc == ORC_OK; gi++) {
+        const uint32_t q = pair_seed0 + (uint32_t)gi * pair_stride;
+        orc_state s;
+        orc_rng_seed(&r, q);
+        orc_new_game(&s, &r);
+        if (half) {
+            orc_invert_players(&s);
+            orc_rng_seed(&r, q + (1u << 30));
+        }
+        s.cur = (int8_t)half;
+        rc = play_out(&t, &s, &r, half, gi, res, status_out, finals160, rounds_out, rec_game_end);
+    }
+    table_close(&t);
+    res->rng_state = r.x;
+    if (rec_n) *rec_n = t.log.n;
     return rc;
 }

@@ -171,6 +171,12 @@ int orc_play_games2(const orc_settings* cfg, int kind0, int kind1, int games, in
                     uint8_t* finals160, uint16_t* rounds_out, uint8_t* rec265, int rec_cap, int* rec_n,
                     int* rec_game_end /* [games] cumulative record count after each game */);
 
+/* one slot of the concurrent-halves form of a mirrored arena (include/azr.h AZR_MIRROR_CONCURRENT): half `half` of the pairs
+ * pair_seed0 + k * pair_stride, k = 0 .. games - 1 */
+int orc_play_half_games(const orc_settings* cfg, int kind0, int kind1, int games, int half, uint32_t pair_seed0, uint32_t pair_stride,
+                        orc_eval_fn eval, void* ctx, orc_eval_fn eval_b, void* ctx_b, orc_results* res, int8_t* status_out,
+                        uint8_t* finals160, uint16_t* rounds_out, uint8_t* rec265, int rec_cap, int* rec_n, int* rec_game_end);
+
 /* bench.py cpu_baseline: `threads` games in parallel, `decisions` decisions each, fp32 CPU net */
 int orc_bench_selfplay(const orc_settings* cfg, const orc_net* net, uint32_t base_seed, int threads, int decisions,
                        uint64_t* sims, uint64_t* evals, double* seconds);

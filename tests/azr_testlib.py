@@ -290,6 +290,27 @@ def orc_play_games2(kind0, kind1, games, mirror, seed, cfg, eval_a, eval_b, rec_
     return res.as_tuple(), st, rd, fin, [rec[a:b].copy() for a, b in zip([0] + list(ends[:-1]), ends)]
 
 
+def orc_play_half_games(kind0, kind1, games, half, pair_seed0, pair_stride, cfg=None, eval_a=None, eval_b=None, rec_cap=8192):
+    """one slot of the concurrent-halves arena (AZR_MIRROR_CONCURRENT): half `half` of the pairs pair_seed0 + k * pair_stride;
+    returns (results tuple, status, rounds, finals, records per game)"""
+    L = oracle()
+    cfg = cfg or default_settings()
+    res = OrcResults()
+    st = np.zeros(games, np.int8)
+    fin = np.zeros((games, 160), np.uint8)
+    rd = np.zeros(games, np.uint16)
+    rec = np.zeros((rec_cap, 265), np.uint8)
+    n = C.c_int(0)
+    ends = np.zeros(games, np.int32)
+    L.orc_play_half_games.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_void_p]
+    rc = L.orc_play_half_games(C.byref(cfg), kind0, kind1, games, half, pair_seed0, pair_stride, eval_a, None, eval_b, None,
+                               C.byref(res), ptr(st), ptr(fin), ptr(rd), ptr(rec), rec_cap, C.byref(n), ptr(ends))
+    assert rc == 0, rc
+    return res.as_tuple(), st, rd, fin, [rec[a:b].copy() for a, b in zip([0] + list(ends[:-1]), ends)]
+
+
 def ref_play_games(kind0, kind1, games, mirror, seed):
     L = ref()
     r6 = (C.c_int * 6)()

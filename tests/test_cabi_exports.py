@@ -46,5 +46,7 @@ def test_header_constants_match_the_binding():
     vals = {k: int(v) for k, v in re.findall(r"\b(AZR_[A-Z0-9_]+)\s*=\s*(-?\d+)", hdr)}
     for name in ("F32", "BF16", "F32X", "F16"):
         assert vals["AZR_NET_" + name] == getattr(P, "NET_" + name), name
-    for name in ("ALPHAZERO", "ALPHAZERO_B"):
+    for name in ("ALPHAZERO", "SCRIPT", "RANDOM", "ALPHAZERO_B"):
         assert vals["AZR_PLAYER_" + name] == getattr(P, "PLAYER_" + name), name
+    for name in ("OFF", "SEQUENTIAL", "CONCURRENT"):
+        assert vals["AZR_MIRROR_" + name] == getattr(P, "MIRROR_" + name), name

@@ -114,8 +114,8 @@ def test_two_net_arena_bit_exact_with_samples(orc, monkeypatch, threads, b_first
     G, per_slot, S, B, base = 6, 2, 12, 1, 5200
     if sb:   # every net launch on the single-image tiles ("2": 4 boards per workgroup, "3": 2, "4": 3), through the leaf-slot map
         monkeypatch.setenv("AZR_TOWER_SB", sb)
-    a = P.Engine(G, blocks=B, sims=S, dtype=P.NET_BF16, threads=threads, max_game_rounds=40)
-    b = P.Engine(G, blocks=B, sims=S, dtype=P.NET_BF16, threads=threads, max_game_rounds=40)
+    a = P.Engine(G, blocks=B, sims=S, dtype=P.NET_BF16, threads=threads, max_game_rounds=40, test_hooks=bool(sb))
+    b = P.Engine(G, blocks=B, sims=S, dtype=P.NET_BF16, threads=threads, max_game_rounds=40, test_hooks=bool(sb))
     a.set_weights(T.make_net_flat(B, seed=31, perturb_bn=True))
     b.set_weights(T.make_net_flat(B, seed=32, perturb_bn=True))
     a.arena_set_opponent(b)
@@ -151,6 +151,86 @@ def test_two_net_arena_bit_exact_with_samples(orc, monkeypatch, threads, b_first
             want_z = np.where(ost[gi] == -2, 0.0, np.where(game[:, 0] == ost[gi], 1.0, -1.0))
             assert (z == want_z).all(), (g, gi)
             assert game.tobytes() in blob, (g, gi)
+            nrec += len(game)
+    assert nrec == len(recs)
+    assert [res["count"], res["draw"], res["win"][0], res["win_and_started"][0], res["win"][1], res["win_and_started"][1]] == list(tot)
+    a.arena_set_opponent(None)
+    a.close(); b.close()
+
+
+# ---- AZR_MIRROR_CONCURRENT: the two games of a mirrored pair at the same time on slots 2j and 2j + 1 (include/azr.h) -------------
+def _half_slot(g, G, base):
+    """slot g of a G-slot concurrent arena = (half, first pair seed, pair stride) of tests/azr_testlib.orc_play_half_games"""
+    return g & 1, base + (g >> 1), G // 2
+
+
+@pytest.mark.parametrize("kinds", [(1, 2), (2, 1), (1, 1)])
+def test_concurrent_pair_halves_script_and_random_bit_exact(orc, kinds):
+    """every slot against the oracle's slot of the same (half, pair seeds) — whose half 0 is anchored on the real reference
+    (tests/test_oracle_vs_ref.py::test_concurrent_halves_anchor_on_the_reference) — and the quota form: pairs assigned statically"""
+    P = pkg()
+    G, per_slot, base = 64, 4, 777
+    eng = P.Engine(G, blocks=1, sims=1, dtype=P.NET_F32, node_capacity=64)
+    res, (n, st, rd, fin) = run_arena(eng, kinds[0], kinds[1], 10 ** 6, per_slot, P.MIRROR_CONCURRENT, base)
+    assert (n == per_slot).all() and eng.counters()["errors"] == 0
+    tot = np.zeros(6, np.int64)
+    for g in range(G):
+        half, q0, stride = _half_slot(g, G, base)
+        r6, ost, ord_, ofin, _ = T.orc_play_half_games(kinds[0], kinds[1], per_slot, half, q0, stride)
+        assert (st[g, :per_slot] == ost).all() and (rd[g, :per_slot] == ord_).all(), g
+        assert (fin[g, :per_slot][:, FM] == ofin[:, FM]).all(), g
+        tot += np.array(r6)
+    assert [res["count"], res["draw"], res["win"][0], res["win_and_started"][0], res["win"][1], res["win_and_started"][1]] == list(tot)
+    # quota: 37 games = 18 pairs over 32 slot pairs -> slot pairs 0..17 play one pair each, the others nothing; G odd leaves the last slot idle
+    res, (n, _, _, _) = run_arena(eng, kinds[0], kinds[1], 37, 0, P.MIRROR_CONCURRENT, base)
+    assert res["count"] == 36 and (n[:36] == 1).all() and (n[36:] == 0).all()
+    eng.close()
+    odd = P.Engine(5, blocks=1, sims=1, dtype=P.NET_F32, node_capacity=64)
+    res, (n, _, _, _) = run_arena(odd, kinds[0], kinds[1], 12, 0, P.MIRROR_CONCURRENT, base)
+    assert res["count"] == 12 and list(n) == [3, 3, 3, 3, 0]
+    odd.close()
+
+
+@pytest.mark.parametrize("threads,b_first", [(2, False), (1, True)])
+def test_concurrent_pair_halves_two_net_arena_bit_exact_with_samples(orc, threads, b_first):
+    """the learn loop's new-vs-old comparison in the concurrent form: results, final states, rounds and every (s, pi, z) record of
+    both AlphaZero players against the oracle's slots, the two DEVICE nets called back per evaluation"""
+    P = pkg()
+    G, per_slot, S, B, base = 6, 2, 12, 1, 6100
+    a = P.Engine(G, blocks=B, sims=S, dtype=P.NET_BF16, threads=threads, max_game_rounds=40)
+    b = P.Engine(G, blocks=B, sims=S, dtype=P.NET_BF16, threads=threads, max_game_rounds=40)
+    a.set_weights(T.make_net_flat(B, seed=31, perturb_bn=True))
+    b.set_weights(T.make_net_flat(B, seed=32, perturb_bn=True))
+    a.arena_set_opponent(b)
+    a.arena_collect_samples(True)
+    k = (P.PLAYER_ALPHAZERO_B, P.PLAYER_ALPHAZERO) if b_first else (P.PLAYER_ALPHAZERO, P.PLAYER_ALPHAZERO_B)
+    res, (n, st, rd, fin) = run_arena(a, k[0], k[1], 10 ** 6, per_slot, P.MIRROR_CONCURRENT, base)
+    assert (n == per_slot).all() and a.counters()["errors"] == 0 and a.counters()["nodes_dropped"] == 0
+    recs = a.drain()
+
+    def make_eval(eng):
+        @T.EVAL_FN
+        def f(ctx, in88, pi, v):
+            x = np.ctypeslib.as_array(in88, shape=(88,)).copy()[None]
+            p, vv = eng.predict(x)
+            C.memmove(pi, p.ctypes.data, 43 * 4)
+            v[0] = float(vv[0])
+        return f
+
+    ea, eb = make_eval(a), make_eval(b)
+    cfg = T.default_settings(mcts_simulations=S, mcts_threads=threads, max_game_rounds=40)
+    tot = np.zeros(6, np.int64)
+    blob = recs.tobytes()
+    nrec = 0
+    for g in range(G):
+        half, q0, stride = _half_slot(g, G, base)
+        r6, ost, ord_, ofin, orec = T.orc_play_half_games(k[0], k[1], per_slot, half, q0, stride, cfg, ea, eb)
+        assert (st[g, :per_slot] == ost).all(), (g, st[g], ost)
+        assert (rd[g, :per_slot] == ord_).all(), g
+        assert (fin[g, :per_slot][:, FM] == ofin[:, FM]).all(), g
+        tot += np.array(r6)
+        for gi, game in enumerate(orec):
+            assert len(game) > 0 and game.tobytes() in blob, (g, gi)
             nrec += len(game)
     assert nrec == len(recs)
     assert [res["count"], res["draw"], res["win"][0], res["win_and_started"][0], res["win"][1], res["win_and_started"][1]] == list(tot)

@@ -206,8 +206,8 @@ def test_tile_shapes_agree_bit_for_bit(monkeypatch, blocks):
     flat = T.make_net_flat(blocks, seed=3, perturb_bn=True)
     out = {}
     for mode in ("0", "1", "2", "3", "4"):
-        monkeypatch.setenv("AZR_TOWER_SB", mode)
-        eng = P.Engine(n, blocks=blocks, sims=1, dtype=P.NET_BF16, node_capacity=64)
+        monkeypatch.setenv("AZR_TOWER_SB", mode)   # a test hook: read by libazr_hip_test.so only; the plan ("1") is the PRODUCT library's
+        eng = P.Engine(n, blocks=blocks, sims=1, dtype=P.NET_BF16, node_capacity=64, test_hooks=mode != "1")
         eng.set_weights(flat)
         out[mode] = eng.predict(x)
         # ragged batches (last workgroup partly filled; in plan mode 700 / 400 boards take the 3- / 2-board tile) and a tiny
@@ -261,8 +261,8 @@ def test_f16_tile_shapes_agree_bit_for_bit(monkeypatch):
     flat = T.make_net_flat(blocks, seed=3, perturb_bn=True)
     out = {}
     for mode in ("0", "1", "2", "3", "4"):
-        monkeypatch.setenv("AZR_TOWER_SB", mode)
-        eng = P.Engine(n, blocks=blocks, sims=1, dtype=P.NET_F16, node_capacity=64)
+        monkeypatch.setenv("AZR_TOWER_SB", mode)   # test hook (libazr_hip_test.so); "1" = the product library's plan
+        eng = P.Engine(n, blocks=blocks, sims=1, dtype=P.NET_F16, node_capacity=64, test_hooks=mode != "1")
         eng.set_weights(flat)
         out[mode] = eng.predict(x)
         for m in (1023, 700, 400, 256, 201, 129, 128, 113, 64, 17, 2, 1):
@@ -290,9 +290,8 @@ def test_split_channel_tower_under_contention(monkeypatch):
     g = np.unique(np.load(os.path.join(T.GOLDEN, "encode.npz"))["in88"], axis=0)
     x = g[np.linspace(0, len(g) - 1, 128).astype(int)].copy()
     flat = T.make_net_flat(blocks, seed=3, perturb_bn=True)
-    monkeypatch.setenv("AZR_TOWER_SC", "0")
-    ref = P.Engine(128, blocks=blocks, sims=1, dtype=P.NET_BF16, node_capacity=64)
-    monkeypatch.setenv("AZR_TOWER_SC", "1")
+    monkeypatch.setenv("AZR_TOWER_SC", "0")   # test hook: the reference engine lives in libazr_hip_test.so, the two under test in the product library
+    ref = P.Engine(128, blocks=blocks, sims=1, dtype=P.NET_BF16, node_capacity=64, test_hooks=True)
     engs = [P.Engine(128, blocks=blocks, sims=1, dtype=P.NET_BF16, node_capacity=64) for _ in range(2)]
     for e in [ref] + engs:
         e.set_weights(flat)
@@ -314,6 +313,69 @@ def test_split_channel_tower_under_contention(monkeypatch):
         assert list(ex.map(hammer, range(3))) == [0, 0, 0]
     for e in [ref] + engs:
         e.close()
+
+
+def test_split_channel_tower_hand_off_that_gives_up_is_recomputed(monkeypatch):
+    """k_tower_sc's hand-off waits for the pair's other workgroups under a spin limit; a launch in which a wait ran out ends with
+    garbage and raises its give-up word, and the guarded one-board-per-workgroup launch queued behind EVERY split-channel launch then
+    recomputes the batch in stream order (csrc/azr_net_bf16.hip net_bf16_forward).  Test hook AZR_TOWER_SC_SPIN=0 (libazr_hip_test.so):
+    a wave that does not find its partners' count at the first look gives up at once.  Results must be the normal path's bits —
+    through azr_nn_predict, device-resident self-play and the two-net arena — and azr_counters.tower_fallbacks counts the recomputes.
+    Also AZR_TOWER_SC_WT=1: the write-through form of the layer images where the plain-store form of a same-XCD pair would run."""
+    P = pkg()
+    blocks = 4
+    g = np.unique(np.load(os.path.join(T.GOLDEN, "encode.npz"))["in88"], axis=0)
+    x = g[np.linspace(0, len(g) - 1, 128).astype(int)].copy()
+    flat = T.make_net_flat(blocks, seed=3, perturb_bn=True)
+    ref = P.Engine(128, blocks=blocks, sims=1, dtype=P.NET_BF16, node_capacity=64)
+    ref.set_weights(flat)
+    want_pi, want_v = ref.predict(x)
+    assert ref.counters()["tower_fallbacks"] == 0
+    monkeypatch.setenv("AZR_TOWER_SC_WT", "1")
+    wt = P.Engine(128, blocks=blocks, sims=1, dtype=P.NET_BF16, node_capacity=64, test_hooks=True)
+    monkeypatch.delenv("AZR_TOWER_SC_WT")
+    monkeypatch.setenv("AZR_TOWER_SC_SPIN", "0")
+    eng = P.Engine(128, blocks=blocks, sims=1, dtype=P.NET_BF16, node_capacity=64, test_hooks=True)
+    monkeypatch.delenv("AZR_TOWER_SC_SPIN")
+    for e in (wt, eng):
+        e.set_weights(flat)
+        for m in (128, 113, 64, 17, 2, 1, 128):
+            pi, v = e.predict(x[:m])
+            assert (pi.view(np.uint32) == want_pi[:m].view(np.uint32)).all() and (v == want_v[:m]).all(), m
+    assert wt.counters()["tower_fallbacks"] == 0
+    fb = eng.counters()["tower_fallbacks"]
+    assert fb >= 1, fb   # 7 launches x 41 hand-offs x up to 64 pairs looked once each: some partner is always late
+    ref.close(); wt.close(); eng.close()
+
+    # device-resident self-play and the two-net arena through the recompute path: byte-identical records / results
+    out = {}
+    for hook in (False, True):
+        if hook:
+            monkeypatch.setenv("AZR_TOWER_SC_SPIN", "0")
+        a = P.Engine(16, blocks=1, sims=8, dtype=P.NET_BF16, threads=2, max_game_rounds=12, test_hooks=hook)
+        b = P.Engine(16, blocks=1, sims=8, dtype=P.NET_BF16, threads=2, max_game_rounds=12, test_hooks=hook)
+        if hook:
+            monkeypatch.delenv("AZR_TOWER_SC_SPIN")
+        a.set_weights(T.make_net_flat(1, seed=31, perturb_bn=True))
+        b.set_weights(T.make_net_flat(1, seed=32, perturb_bn=True))
+        a.selfplay_start_games(4242, 24)
+        while a.counters()["games_finished"] < 24:
+            a.selfplay_run(64)
+        recs = a.drain()
+        a.arena_set_opponent(b)
+        a.arena_collect_samples(True)
+        a.arena_start(P.PLAYER_ALPHAZERO, P.PLAYER_ALPHAZERO_B, 16, 0, P.MIRROR_CONCURRENT, 99)
+        for _ in range(4000):
+            if a.arena_run(64):
+                break
+        else:
+            raise AssertionError("arena did not finish")
+        canon = lambda r: np.sort(np.ascontiguousarray(r).view("S265").ravel()).tobytes()   # noqa: E731  (games finish in any order within a pass)
+        out[hook] = (canon(recs), a.arena_results(), canon(a.drain()), a.counters()["tower_fallbacks"])
+        a.arena_set_opponent(None)
+        a.close(); b.close()
+    assert out[False][3] == 0 and out[True][3] >= 1, (out[False][3], out[True][3])
+    assert out[False][:3] == out[True][:3]
 
 
 def oracle_search(orc, flat, blocks, sims, states, seeds, threads=16):

@@ -127,7 +127,7 @@ def test_step_matches_torch_graph(blocks, bs, gemm, monkeypatch):
             break
     else:
         pytest.fail("no record seed with a ReLU margin of 1e-6")
-    eng = P.Engine(8, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64)
+    eng = P.Engine(8, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64, test_hooks=gemm in ("r2", "f32"))   # the switches exist in libazr_hip_test.so only
     eng.set_weights(flat)
     lp, lv = eng.train_batch(rec)
     g = eng.train_grads()
@@ -172,7 +172,7 @@ def test_fused_normalise_kernels_change_no_bit(monkeypatch):
         rec = records(3 * bs, seed=17)
         for mode in ("1", "0"):
             monkeypatch.setenv("AZR_TRAIN_FUSE_APPLY", mode)
-            eng = P.Engine(8, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64)
+            eng = P.Engine(8, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64, test_hooks=True)   # (both sides: AZR_TRAIN_CONVQ=0 is a hook too)
             eng.set_weights(flat)
             losses = [eng.train_batch(rec[t * bs:(t + 1) * bs]) for t in range(3)]
             out[mode] = (eng.get_weights(), eng.train_grads(), losses)
@@ -234,7 +234,7 @@ def test_conv_kernel_families_at_the_reference_batch(monkeypatch):
             monkeypatch.setenv("AZR_TRAIN_FUSE", "0")
         if mode == "f32":
             monkeypatch.setenv("AZR_TRAIN_GEMM", "f32")
-        eng = P.Engine(8, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64)
+        eng = P.Engine(8, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64, test_hooks=mode != "default")
         eng.set_weights(flat)
         lp, lv = eng.train_batch(rec)
         g = eng.train_grads().astype(np.float64)

@@ -19,11 +19,13 @@ from gpu_common import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world,blocks", [(2, 2), (4, 1)])
-def test_data_parallel_step_equals_single_gpu_step(tmp_path, world, blocks):
+@pytest.mark.parametrize("world,blocks,bs", [(2, 2, 64), (4, 1, 64), (4, 2, 256)])
+def test_data_parallel_step_equals_single_gpu_step(tmp_path, world, blocks, bs):
+    """(4, 2, 256): 64-record shares — the per-rank shape of configs[4] (BATCH_SIZE 512 over 8 GPUs): the small-batch conv kernel and
+    8-board weight-gradient slices in four PROCESSES over gloo (world 8 x 64 records in one process: tests/test_gpu_rehearsal.py)"""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "dp.npz")
-    env = dict(os.environ, DP_BLOCKS=str(blocks), DP_BS="64", DP_N="200")
+    env = dict(os.environ, DP_BLOCKS=str(blocks), DP_BS=str(bs), DP_N=str(3 * bs + 8))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "helpers", "dp_train_worker.py"), out]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)

@@ -101,11 +101,11 @@ def test_host_stepped_arena_through_the_player_seam():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dp", ["1", "-1"])
+@pytest.mark.parametrize("dp", ["1", "0"])
 def test_two_rank_learn_iteration(tmp_path, dp):
     """the N > 1 learn path (BASELINE configs[4]) rehearsed with 2 ranks on this box's one GPU over gloo: sharded
-    self-play, all_gather of the records, training (--dp 1: data-parallel optimiser step on both ranks; --dp -1, the
-    default: at 32 records per rank rank 0 trains and broadcasts the weights), sharded arena + benchmark with reduced
+    self-play, all_gather of the records, training (--dp 1: data-parallel optimiser step on both ranks; --dp 0, the
+    default: rank 0 trains and broadcasts the weights), sharded arena + benchmark with reduced
     GameResults; rank 0 writes the reference's files"""
     import socket
     import subprocess

@@ -82,3 +82,18 @@ def test_players_and_game_driver_bit_exact(orc, kinds):
             b = T.orc_play_games(kinds[0], kinds[1], 8, mirror, seed)
             assert a[0] == b[0] and (a[1] == b[1]).all() and (a[2] == b[2]).all()
             assert (a[3][:, FM] == b[3][:, FM]).all() and a[4] == b[4]
+
+
+@pytest.mark.parametrize("kinds", [(1, 2), (2, 1), (1, 1)])
+def test_concurrent_halves_anchor_on_the_reference(orc, kinds):
+    """AZR_MIRROR_CONCURRENT (include/azr.h): half 0 of the pair with seed q IS the first game a reference thread plays on a
+    global engine seeded q (deal and dice from one stream) — results, final state, rounds, RNG position; half 1 is a game of its own
+    (mirrored deal, player 1 starts, own dice stream) and a function of (q, half) alone."""
+    for q in range(300, 320):
+        a = T.ref_play_games(kinds[0], kinds[1], 1, 1, q)
+        b = T.orc_play_half_games(kinds[0], kinds[1], 1, 0, q, 1)
+        assert a[0] == b[0] and (a[1] == b[1]).all() and (a[2] == b[2]).all() and (a[3][:, FM] == b[3][:, FM]).all()
+        h1 = T.orc_play_half_games(kinds[0], kinds[1], 1, 1, q, 1)
+        h1b = T.orc_play_half_games(kinds[0], kinds[1], 3, 1, q - 14, 7)   # the same pair as the third game of another slot
+        assert h1[0][0] == 1 and h1[1][0] == h1b[1][2] and (h1[3][0][FM] == h1b[3][2][FM]).all()
+        assert h1[0][3] == 0 and h1[0][5] == h1[0][4]   # player 1 started: only its wins count as "won and started"

@@ -11,7 +11,7 @@ import time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 P = importlib.import_module("alphazero-risk_amd")
 if os.environ.get("AZR_EXP_LIB"):   # a timing-experiment build of the same sources (never the product library)
-    P.binding.lib_path = lambda: os.environ["AZR_EXP_LIB"]
+    P.binding.lib_path = lambda test_hooks=False: os.environ["AZR_EXP_LIB"]
 
 
 def main():

@@ -12,12 +12,12 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 P = importlib.import_module("alphazero-risk_amd")
 if os.environ.get("AZR_EXP_LIB"):   # a timing-experiment build of the same sources (never the product library)
-    P.binding.lib_path = lambda: os.environ["AZR_EXP_LIB"]
+    P.binding.lib_path = lambda test_hooks=False: os.environ["AZR_EXP_LIB"]
 
 
 def main():
     ns = [int(x) for x in sys.argv[1:]] or [1, 16, 64, 100, 128, 200, 256]
-    eng = P.Engine(256, blocks=20, sims=1, dtype=P.NET_BF16, node_capacity=64)
+    eng = P.Engine(256, blocks=20, sims=1, dtype=P.NET_BF16, node_capacity=64, test_hooks=not os.environ.get("AZR_EXP_LIB"))   # AZR_TOWER_SC is a test hook
     eng.init_random(1)
     rng = np.random.default_rng(1)
     x = np.zeros((256, 88), np.uint8)

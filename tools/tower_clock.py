@@ -10,12 +10,12 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 P = importlib.import_module("alphazero-risk_amd")
 if os.environ.get("AZR_EXP_LIB"):   # a timing-experiment build of the same sources (never the product library)
-    P.binding.lib_path = lambda: os.environ["AZR_EXP_LIB"]
-L = P.load_library()
+    P.binding.lib_path = lambda test_hooks=False: os.environ["AZR_EXP_LIB"]
+L = P.load_library(test_hooks=not os.environ.get("AZR_EXP_LIB"))   # AZR_TOWER_SB is a test hook: the engines below live in the same library
 L.azr_debug_tower_clock.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 sizes = [int(x) for x in sys.argv[1:]] or [256, 512, 768, 1024, 2048, 4096]
 for n in sizes:
-    e = P.Engine(n, blocks=20, sims=100, dtype=P.NET_BF16, threads=1)
+    e = P.Engine(n, blocks=20, sims=100, dtype=P.NET_BF16, threads=1, test_hooks=not os.environ.get("AZR_EXP_LIB"))   # AZR_TOWER_SB is a test hook
     e.init_random(1)
     e.selfplay_start(1)
     e.selfplay_run(20)

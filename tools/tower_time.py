@@ -9,14 +9,14 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 P = importlib.import_module("alphazero-risk_amd")
 if os.environ.get("AZR_EXP_LIB"):   # a timing-experiment build of the same sources (never the product library)
-    P.binding.lib_path = lambda: os.environ["AZR_EXP_LIB"]
+    P.binding.lib_path = lambda test_hooks=False: os.environ["AZR_EXP_LIB"]
 G, T = int(sys.argv[1]), int(sys.argv[2])
 passes = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 modes = sys.argv[4:] or ["1"]
 for rep in range(2):
     for mode in modes:
         os.environ["AZR_TOWER_SB"] = mode
-        e = P.Engine(G, blocks=20, sims=100, dtype=P.NET_BF16, threads=T)
+        e = P.Engine(G, blocks=20, sims=100, dtype=P.NET_BF16, threads=T, test_hooks=not os.environ.get("AZR_EXP_LIB"))   # AZR_TOWER_SB is a test hook
         e.init_random(1)
         e.selfplay_start(1)
         e.selfplay_run(60)

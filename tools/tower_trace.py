@@ -11,7 +11,7 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 P = importlib.import_module("alphazero-risk_amd")
 if os.environ.get("AZR_EXP_LIB"):   # a timing-experiment build of the same sources (never the product library)
-    P.binding.lib_path = lambda: os.environ["AZR_EXP_LIB"]
+    P.binding.lib_path = lambda test_hooks=False: os.environ["AZR_EXP_LIB"]
 L = P.load_library()
 L.azr_debug_tower_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
 for n in [int(x) for x in sys.argv[1:]] or [1024, 4096]:

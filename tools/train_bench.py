@@ -35,7 +35,7 @@ def main():
     if a.torch:   # torch bundles its own HIP runtime: let it initialise the device before the C-ABI library does
         import torch
         torch.cuda.init()
-    eng = P.Engine(64, blocks=a.blocks, sims=8, dtype=P.NET_BF16)
+    eng = P.Engine(64, blocks=a.blocks, sims=8, dtype=P.NET_BF16, test_hooks=bool(a.native))   # AZR_DP_LOOPBACK is a test hook (libazr_hip_test.so)
     eng.init_random(1)
     # records from real self-play positions
     eng.selfplay_start(7)
