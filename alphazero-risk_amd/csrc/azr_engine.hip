@@ -299,7 +299,15 @@ struct StepCount {
 // when somebody asks (azr_selfplay_counters).  One shared row bumped with atomics made every pass end with G x 4..9
 // same-address device atomics, which the L2 retires one by one (~12 ns each): 20 us of a 47-us tree step at 512 games.
 // `count_active`: host-stepped search only (azr_mcts_leaves reads the number of games that wait for the net).
-__device__ __forceinline__ void flush_counters(const Dev& E, int g, const Ctl& c, const StepCount& k, bool count_active)
+// The row is read-modify-write, and the read is issued when the wave STARTS (counters_begin): at the end of a step the wave's stores
+// are still draining, and a load issued behind them waits for every one of them (memory operations of a wave retire in order) —
+// 3.7 us of an average mid-game wave, 9 us of the slow ones the launch waits for (profiles/r03_tree_step_profile.txt).
+__device__ __forceinline__ unsigned long long counters_begin(const Dev& E, int g)
+{
+    const uint32_t l = lane_id();
+    return l < 9 ? reinterpret_cast<const unsigned long long*>(E.counters + g)[l] : 0ull;
+}
+__device__ __forceinline__ void flush_counters(const Dev& E, int g, const Ctl& c, const StepCount& k, bool count_active, unsigned long long base)
 {
     if (count_active && lane_id() == 0 && c.pending) atomicAdd(E.active, 1u);
     const uint32_t l = lane_id();
@@ -308,7 +316,7 @@ __device__ __forceinline__ void flush_counters(const Dev& E, int g, const Ctl& c
     d = l == 5 ? k.samples : d; d = l == 6 ? k.drop : d; d = l == 7 ? k.err : d; d = l == 8 ? k.ringdrop : d;
     if (l < 9 && d) {
         unsigned long long* row = reinterpret_cast<unsigned long long*>(E.counters + g);
-        row[l] += d;
+        row[l] = base + d;
     }
 }
 
@@ -339,7 +347,7 @@ __device__ __forceinline__ void consume_pending(const Dev& E, int g, const Tree&
         k.evals++;
         const uint32_t plen = plen_get(c, th);
         if (plen > 0) {  // plen == 0: this was setRootState's root expansion (not a simulation)
-            tree_backup(thread_tree(t, th), plen, v);
+            tree_backup(thread_tree(t, th), plen, v, false);
             c.sims_done++;
             k.sims++;
         }
@@ -394,6 +402,9 @@ __device__ __forceinline__ int run_descents(const Dev& E, int g, const Tree& t0,
                 if (l < 16) reinterpret_cast<uint32_t*>(E.leaf_key + slot * GREC)[l] = kd;
                 if (l == 0) { E.leaf_valid[slot] = valid; E.leaf_hash[slot] = h; }
                 leaf = true;
+#ifdef AZR_EXP_LATE_FENCE
+                wave_mem_sync();   // (experiment: one fence per descent instead of one per level)
+#endif
                 TP(11);
                 break;
             }
@@ -491,6 +502,7 @@ __global__ __launch_bounds__(64) void k_tree_step(Dev E)
     Ctl c;
     ctl_load(c, &E.ctl[g]);
     if (c.mode == 0 || (!SELFPLAY && c.search_done)) return;
+    const unsigned long long cnt0 = counters_begin(E, g);
     Tree t = tree_of(E, g);
     const Rules R = E.rules;
     const Search S = E.search;
@@ -568,7 +580,7 @@ __global__ __launch_bounds__(64) void k_tree_step(Dev E)
     TP(19);
     ctl_store(c, &E.ctl[g]);
     TP(20);
-    flush_counters(E, g, c, k, !SELFPLAY);
+    flush_counters(E, g, c, k, !SELFPLAY, cnt0);
     TP(21);
     // self-play tail (quota mode, slots going idle): the net of this pass runs on the waiting leaf slots only
     if (SELFPLAY && E.sp_compact && c.pending) {
@@ -594,6 +606,7 @@ __global__ __launch_bounds__(64) void k_arena_step(Dev E)
     Ctl c;
     ctl_load(c, &E.ctl[g]);
     if (c.mode != 3 || c.arena_state == 2) return;
+    const unsigned long long cnt0 = counters_begin(E, g);
     Tree t = tree_of(E, g);
     const Rules R = E.rules;
     const Search S = E.search;
@@ -775,7 +788,7 @@ __global__ __launch_bounds__(64) void k_arena_step(Dev E)
         if (lane_id() == 0) { dst[0] = sp[0]; dst[1] = sp[1]; }
     }
     ctl_store(c, &E.ctl[g]);
-    flush_counters(E, g, c, k, false);
+    flush_counters(E, g, c, k, false, cnt0);
 }
 
 __global__ __launch_bounds__(64) void k_arena_start(Dev E)

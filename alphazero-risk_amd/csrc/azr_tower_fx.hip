@@ -340,7 +340,6 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_fx(const uint8_t* __restri
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) acc[mt][nt] = f32x4{0, 0, 0, 0};
-        const float2 fnext = *reinterpret_cast<const float2*>(fold + 14 + (size_t)L * 2 * NF + 2 * tid);   // (see the epilogue)
         uint32_t ap[MT];        // LDS byte address of this lane's fragment of tile mt at k-step 0 of the current tap
         f16x8 ah[MT], al[MT];   // ... and the fragments (hi plane, lo' plane) of the k-step about to run
         {
@@ -369,6 +368,8 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_fx(const uint8_t* __restri
         conv_tap<NB, 1, 1>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
         conv_tap<NB, 1, 2>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
         conv_tap<NB, 1, 3>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
+        // this layer's folded BN scale / shift (see the epilogue): requested 40 k-steps ahead of their use, not a whole layer
+        const float2 fnext = *reinterpret_cast<const float2*>(fold + 14 + (size_t)L * 2 * NF + 2 * tid);
         conv_tap<NB, 1, 4>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
         conv_tap<NB, 1, 5>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
         conv_tap<NB, 1, 6>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
@@ -378,37 +379,38 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_fx(const uint8_t* __restri
         // this layer's folded BN scale / shift go through LDS (2 registers per lane over the k-steps instead of 32)
         *reinterpret_cast<float2*>(foldl + 2 * tid) = fnext;
         __syncthreads();        // every wave has read the planes for the last time
-        float4 sc[NT], sh[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-            sc[nt] = *reinterpret_cast<const float4*>(foldl + wave * 64 + g * 4 + nt * 16);
-            sh[nt] = *reinterpret_cast<const float4*>(foldl + NF + wave * 64 + g * 4 + nt * 16);
-        }
+        // (scale / shift of a column tile are read where they are used: 8 live registers instead of 32)
         if (L & 1) {    // second conv of a block: + shortcut (the block's input, fp32 in registers); the output is the next block's input
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++)
+            for (int nt = 0; nt < NT; nt++) {
+                const float4 sc = *reinterpret_cast<const float4*>(foldl + wave * 64 + g * 4 + nt * 16);
+                const float4 sh = *reinterpret_cast<const float4*>(foldl + NF + wave * 64 + g * 4 + nt * 16);
 #pragma unroll
-                for (int nt = 0; nt < NT; nt++) {
+                for (int mt = 0; mt < MT; mt++) {
                     uint2 ohi, olo;
-                    bn_relu_split<true>(acc[mt][nt], sc[nt], sh[nt], res[mt][nt], ohi, olo);
+                    bn_relu_split<true>(acc[mt][nt], sc, sh, res[mt][nt], ohi, olo);
                     if (c < pad_from<NB>(mt)) {
                         *reinterpret_cast<uint2*>(bufH + eoff + mt * 16 * ROWB + nt * 32) = ohi;
                         *reinterpret_cast<uint2*>(bufL + eoff + mt * 16 * ROWB + nt * 32) = olo;
                     }
                 }
+            }
         } else {
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++)
+            for (int nt = 0; nt < NT; nt++) {
+                const float4 sc = *reinterpret_cast<const float4*>(foldl + wave * 64 + g * 4 + nt * 16);
+                const float4 sh = *reinterpret_cast<const float4*>(foldl + NF + wave * 64 + g * 4 + nt * 16);
 #pragma unroll
-                for (int nt = 0; nt < NT; nt++) {
+                for (int mt = 0; mt < MT; mt++) {
                     uint2 ohi, olo;
                     f32x4 t;
-                    bn_relu_split<false>(acc[mt][nt], sc[nt], sh[nt], t, ohi, olo);
+                    bn_relu_split<false>(acc[mt][nt], sc, sh, t, ohi, olo);
                     if (c < pad_from<NB>(mt)) {
                         *reinterpret_cast<uint2*>(bufH + eoff + mt * 16 * ROWB + nt * 32) = ohi;
                         *reinterpret_cast<uint2*>(bufL + eoff + mt * 16 * ROWB + nt * 32) = olo;
                     }
                 }
+            }
         }
         __syncthreads();        // the new planes are complete
     }

@@ -2223,9 +2223,12 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
                 fwd_parts = (BS + 1) / 2;
                 hipLaunchKernelGGL((t_conv_rs<1, 2, 2, true>), dim3(fwd_parts), dim3(256), 0, st, Parts{{c->af[0], c->af[1], nullptr}}, Wpf(l), Yl(l), BS,
                                    BwdFuse{nullptr, nullptr, nullptr, nullptr, nullptr, c->part}, 1.0f / FWD_WSCALE, ProFuse{});
-            } else if (f16) hipLaunchKernelGGL((t_conv_rs<1, 2, 0, true>), dim3((BS + 1) / 2), dim3(256), 0, st, Parts{{c->af[0], c->af[1], nullptr}}, Wpf(l), Yl(l), BS,
+            }
+#ifdef AZR_TEST_HOOKS   // older formulations of the same conv (AZR_TRAIN_FUSE=0, AZR_TRAIN_FWD=bf16): compiled into libazr_hip_test.so only
+            else if (f16) hipLaunchKernelGGL((t_conv_rs<1, 2, 0, true>), dim3((BS + 1) / 2), dim3(256), 0, st, Parts{{c->af[0], c->af[1], nullptr}}, Wpf(l), Yl(l), BS,
                                         BwdFuse{}, 1.0f / FWD_WSCALE, ProFuse{});
             else hipLaunchKernelGGL((t_conv_rs<1, 3>), dim3((BS + 1) / 2), dim3(256), 0, st, Ap(l - 1), Wpf(l), Yl(l), BS, BwdFuse{}, 1.0f, ProFuse{});
+#endif
         } else gemm<false, false, 64, 1, 0>(st, Al(l - 1), KC, Wl(l), NF, Yl(l), NF, M, NF, KC);
         const int Rf = fwd_parts ? fwd_parts : R;
         if (!fwd_parts) hipLaunchKernelGGL((t_bn_stats<false>), dim3(R), dim3(1024), 0, st, Yl(l), M, c->part);
@@ -2328,12 +2331,18 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         hipLaunchKernelGGL((t_bn_bwd_apply<false>), dim3(g4), dim3(256), 0, st, dOut, Al(l), Yl(l), c->mean + l * NF, c->istd + l * NF, bn, c->sums,
                            invM, sb ? (float*)nullptr : c->dY, second ? c->DS : (float*)nullptr, M, sb ? c->dyp[0] : nil16, c->dyp[1]);
         // dW = col(input)^T x dY  (implicit im2col, split-K over the M rows)
+        // (In the product library this point is reached only by batches whose row count is no multiple of the 32-deep k-tile: the fp32-MFMA
+        //  GEMMs.  The split-bf16 kernels WITHOUT the staging-path fusions are older formulations, compiled into libazr_hip_test.so only.)
+#ifdef AZR_TEST_HOOKS
         if (sb) {
             hipLaunchKernelGGL(t_wgrad_rs, dim3(64 * c->wg_slices), dim3(64), Wg::LDS_BYTES, st, apP, dyP, c->wpart, M, c->wg_slices, c->wg_rows);
-        } else gemm<true, false, 128, 1, 0>(st, Al(l - 1), KC, c->dY, NF, c->wpart, NF, KC, NF, M, c->nz, c->kchunk, wn);
+        } else
+#endif
+        gemm<true, false, 128, 1, 0>(st, Al(l - 1), KC, c->dY, NF, c->wpart, NF, KC, NF, M, c->nz, c->kchunk, wn);
         hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, sb ? c->wg_slices : c->nz, wn, Gl(l));
         // d(input) = transposed conv of dY with W: the same implicit GEMM with negated taps and W read as [tap][co] x [ci]
         fused_parts = 0;
+#ifdef AZR_TEST_HOOKS
         if (fuse && l >= 2) {   // + the shortcut gradient (first conv of a block), + stage 1 of layer l - 1's BN backward
             fused_parts = (BS + 1) / 2;
             hipLaunchKernelGGL((t_conv_rs<2, 2, 1>), dim3(fused_parts), dim3(256), 0, st, dyP, Wpb(l), dIn, BS,
@@ -2342,7 +2351,9 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
             continue;
         }
         if (sb) hipLaunchKernelGGL((t_conv_rs<2, 2>), dim3((BS + 1) / 2), dim3(256), 0, st, dyP, Wpb(l), dIn, BS, BwdFuse{}, 1.0f, ProFuse{});
-        else gemm<false, true, 64, 2, 3>(st, c->dY, KC, Wl(l), NF, dIn, NF, M, NF, KC);
+        else
+#endif
+        gemm<false, true, 64, 2, 3>(st, c->dY, KC, Wl(l), NF, dIn, NF, M, NF, KC);
         if (!second) hipLaunchKernelGGL(t_add, dim3(g4), dim3(256), 0, st, dIn, c->DS, act / 4);  // + shortcut gradient
     }
     // the weight-gradient branch joins: the stem below reuses its split-K buffer, and the gradient vector is complete behind it

@@ -101,35 +101,57 @@ __device__ __forceinline__ uint32_t key_hash(uint32_t kd)
     return h == 0 ? 1u : h;
 }
 
+// One round of the table's probe sequence, 16 slots at a time: lanes 0..15 (and their copies 16..63) read the 16 consecutive slots
+// from `slot` on in ONE coalesced request.  Returns the candidates — slots whose tag matches, in probe order, up to the first empty
+// slot — as a bit mask, `e` holding each lane's entry; `ended` = the sequence ends inside this round (an empty slot was seen).
+// A lookup walked the sequence one dependent load per slot; a clustered table (after a trim re-inserts the survivors) made that
+// the longest segment of the slow waves a launch waits for (20 us, profiles/r03_tree_step_profile.txt).  Same slots, same order,
+// same first hit: results do not change.
+__device__ __forceinline__ uint32_t probe16(const Tree& t, uint32_t slot, uint32_t tag, uint32_t& e, bool& ended)
+{
+    e = t.table[(slot + (lane_id() & 15u)) & (uint32_t)(t.H - 1)];
+    const uint32_t empty = (uint32_t)ballot64(e == 0) & 0xffffu;
+    uint32_t match = (uint32_t)ballot64(e != 0 && (e >> 16) == tag) & 0xffffu;
+    ended = empty != 0;
+    if (ended) match &= (1u << __builtin_ctz(empty)) - 1u;
+    return match;
+}
+
 // StateSimulationsStorage::exist + getStateSimulation: node index of the record `kd`, or NO_NODE
 __device__ __forceinline__ uint32_t tree_lookup(const Tree& t, uint32_t kd, uint32_t h)
 {
     const uint32_t tag = h >> 16;
     uint32_t slot = h & (uint32_t)(t.H - 1);
-    for (int probes = 0; probes < t.H; probes++) {
-        uint32_t e = rfl(t.table[slot]);
-        if (e == 0) return NO_NODE;
-        if ((e >> 16) == tag) {
-            uint32_t idx = (e & 0xffffu) - 1u;
+    for (int probes = 0; probes < t.H; probes += 16) {
+        uint32_t e;
+        bool ended;
+        uint32_t match = probe16(t, slot, tag, e, ended);
+        while (match) {
+            const uint32_t j = (uint32_t)__builtin_ctz(match);
+            match &= match - 1u;
+            const uint32_t idx = (rdl(e, j) & 0xffffu) - 1u;
             uint32_t nk = reinterpret_cast<const uint32_t*>(node_ptr(t, idx))[lane_id() & 15u];
             if (ballot64(nk != kd) == 0) return idx;
         }
-        slot = (slot + 1) & (uint32_t)(t.H - 1);
+        if (ended) return NO_NODE;
+        slot = (slot + 16) & (uint32_t)(t.H - 1);
     }
     return NO_NODE;
 }
 
 __device__ __forceinline__ void tree_insert(const Tree& t, uint32_t h, uint32_t idx)
 {
-    uint32_t slot = h & (uint32_t)(t.H - 1);
-    for (int probes = 0; probes < t.H; probes++) {
-        uint32_t e = rfl(t.table[slot]);
-        if (e == 0) {
-            if (lane_id() == 0) t.table[slot] = (h & 0xffff0000u) | (idx + 1u);
+    const uint32_t mask = (uint32_t)(t.H - 1);
+    uint32_t slot = h & mask;
+    for (int probes = 0; probes < t.H; probes += 16) {   // the first empty slot of the probe sequence, 16 slots per round trip
+        const uint32_t e = t.table[(slot + (lane_id() & 15u)) & mask];
+        const uint32_t empty = (uint32_t)ballot64(e == 0) & 0xffffu;
+        if (empty) {
+            if (lane_id() == 0) t.table[(slot + (uint32_t)__builtin_ctz(empty)) & mask] = (h & 0xffff0000u) | (idx + 1u);
             wave_mem_sync();
             return;
         }
-        slot = (slot + 1) & (uint32_t)(t.H - 1);
+        slot = (slot + 16) & mask;
     }
 }
 
@@ -291,17 +313,21 @@ __device__ __forceinline__ uint32_t tree_lookup_node(const Tree& t, uint32_t kd,
 {
     const uint32_t tag = h >> 16;
     uint32_t slot = h & (uint32_t)(t.H - 1);
-    for (int probes = 0; probes < t.H; probes++) {
-        uint32_t e = rfl(t.table[slot]);
-        if (e == 0) return NO_NODE;
-        if ((e >> 16) == tag) {
-            uint32_t idx = (e & 0xffffu) - 1u;
+    for (int probes = 0; probes < t.H; probes += 16) {
+        uint32_t e;
+        bool ended;
+        uint32_t match = probe16(t, slot, tag, e, ended);
+        while (match) {
+            const uint32_t j = (uint32_t)__builtin_ctz(match);
+            match &= match - 1u;
+            const uint32_t idx = (rdl(e, j) & 0xffffu) - 1u;
             const uint8_t* n = node_ptr(t, idx);
             uint32_t nk = reinterpret_cast<const uint32_t*>(n)[lane_id() & 15u];
             nr = node_load(n);
             if (ballot64(nk != kd) == 0) return idx;
         }
-        slot = (slot + 1) & (uint32_t)(t.H - 1);
+        if (ended) return NO_NODE;
+        slot = (slot + 16) & (uint32_t)(t.H - 1);
     }
     return NO_NODE;
 }
@@ -336,7 +362,9 @@ __device__ __forceinline__ uint32_t tree_select(const Tree& t, uint32_t idx, con
     }
     const uint32_t mv = (ties & (ties - 1)) == 0 ? (uint32_t)ctz64(ties) : umap_first(valid, ties, scratch);
     if (l == mv) reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(n) + ND_N)[l] = W + ACT_ONE;  // sv.active_N++
+#ifndef AZR_EXP_LATE_FENCE
     wave_mem_sync();
+#endif
     return mv;
 }
 // NNOutputData::normalize (alphazero_nn_data.cpp:3-27): sequential fp32 sum over the legal entries, index order
@@ -376,17 +404,18 @@ __device__ __forceinline__ uint32_t tree_expand(const Tree& t, Ctl& c, uint32_t 
         reinterpret_cast<float*>(n + ND_Q)[l] = 0.0f;
         reinterpret_cast<uint32_t*>(n + ND_N)[l] = 0u;
     }
-    wave_mem_sync();
-    tree_insert(t, h, idx);
+    tree_insert(t, h, idx);   // (ends with the fence that makes the node's body AND its table entry visible to this wave's later loads)
     return idx;
 }
 
 // SimulationValue::addValue / StateSimulations::addValue along the whole path (alphazero_mcts.cpp:8-21,55-60,
 // 367-375).  Lane i handles path entry i; the value's sign at entry i is flipped once for every "player changed"
 // at entries >= i.
-__device__ __forceinline__ void tree_backup(const Tree& t, uint32_t path_len, float leaf_value)
+// `fresh_path`: the path entries were written by lane 0 in THIS launch (a descent that ended in a finished game) and have to be made
+// visible to the other lanes first; a leaf's path was written by the launch that found the leaf.
+__device__ __forceinline__ void tree_backup(const Tree& t, uint32_t path_len, float leaf_value, bool fresh_path = true)
 {
-    wave_mem_sync();     // path entries were written by lane 0
+    if (fresh_path) wave_mem_sync();
     uint32_t carry = 0;  // parity of flips below the current chunk
     for (int base = ((int)path_len - 1) & ~63; base >= 0; base -= 64) {
         uint32_t i = (uint32_t)base + lane_id();

