@@ -5,26 +5,28 @@
 // fp32 rate but differs from an fp32 evaluation by up to 1e-2 in pi / v; the fp32 VALU path is exact and slow.  This kernel is
 // the fp32-equivalent path at matrix-core rate.
 //
-// How.  Every 3x3 conv operand x (activation or weight) is held as an fp16 PAIR  x = hi + lo' * 2^-11,  hi = rne16(x),
-// lo' = rne16((x - hi) * 2^11)  (the low part is kept pre-scaled: a plain fp16 low part of an O(0.03) weight would be an fp16
-// subnormal).  22 significand bits per operand; a product a * w = ah*wh + 2^-11 (ah*wl' + al'*wh) + 2^-22 al'*wl' and the last
-// term is dropped.  tools/f32x_split_study.py (float64 emulation, B = 20, the 128 boards of the parity test): max |d pi|
-// 1.7e-7, max |d v| 3.7e-7 — the size of rounding the operands to fp32 (1.2e-7); bf16 pairs with the same 3 passes stop at
+// How.  Every 3x3 conv operand x (activation or weight) is held as an fp16 PAIR  x = hi + lo,  hi = rne16(x), lo = rne16(x - hi):
+// 22 significand bits per operand (the low part of a value below 2^-3 is an fp16 subnormal, which the matrix core takes at full
+// value — profiles/r03_mfma_round_probe.txt — so its absolute error is 2^-25: the size of rounding the operand to fp32).  A product
+// a * w = ah*wh + ah*wl + al*wh + al*wl and the last term is dropped.  tools/f32x_split_study.py (float64 emulation of the split
+// alone, B = 20, the 128 boards of the parity test): max |d pi| 2.3e-7, max |d v| 3.5e-7 (with the low parts pre-scaled by 2^11, the
+// round-3 form: 1.6e-7 / 2.9e-7 — no difference that matters against the 2e-5 gate); bf16 pairs with the same 3 passes stop at
 // 2.2e-5 / 3.4e-5, six bf16 passes would be needed for what three fp16 passes give.
-// Per layer, ONE set of fp32 accumulators:
-//     phase 1 (cross terms): for all 72 k-steps   acc += wh * al' ;  acc += wl' * ah        (2 MFMAs per tile)
-//     acc *= 2^-11  (exact)
-//     phase 2 (main term):   for all 72 k-steps   acc += wh * ah
+// Per layer, ONE set of fp32 accumulators and ONE pass over the 72 k-steps, 12 MFMAs per row tile and k-step:
+//     acc += wh * ah ;  acc += wh * al ;  acc += wl * ah          (products of fp16 values are exact in the fp32 accumulate)
 //     epilogue: folded BN (fp32 fma), shortcut add in fp32 (the block input stays in fp32 REGISTERS), ReLU, split into the pair
-// i.e. 3 x the MFMAs of the bf16 tower on v_mfma_f32_16x16x32_f16 (products of fp16 values are exact in the fp32 accumulate).
+// i.e. 3 x the MFMAs of the bf16 tower on v_mfma_f32_16x16x32_f16.  (Round 3 ran the cross terms as a phase of their own, at 2^11
+// times their weight, and re-read the wh half of the stream for the main term: 12 weight fragments per tile and k-step pair where
+// this form loads 8 — the kernel was held by the weight stream through the CU's L1, 42 B/clk of 64 — and 144 k-steps of loop
+// overhead where this has 72.)
 // The stem (K = 9 x 13) runs on the fp32-input MFMA v_mfma_f32_16x16x4_f32 from fp32 planes and fp32 weights: exact fp32.
-// The heads read the reconstructed fp32 activations (hi + lo' 2^-11 is exact in fp32) and run the fp32 fma chains of k_heads.
+// The heads read the reconstructed fp32 activations (hi + lo is exact in fp32) and run the fp32 fma chains of k_heads.
 //
 // Structure = k_tower_sb (azr_tower_sb.hip): one workgroup of 4 waves (one per SIMD) owns NB boards for the whole net, the
 // activations never leave LDS (two planes: hi image, lo' image), waves split the 256 output channels (4 tiles of 16 each), weight
 // fragments stream global -> registers through a ring that never drains, border-class row order with skipped (tile, tap)
-// pairs, a layer's 144 k-steps fully unrolled.  Packed weights: per layer and k-step [16 column tiles of wh | 16 of wl']
-// (phase 2 re-reads the wh halves of the same stream).
+// pairs, a layer's 72 k-steps fully unrolled.  Packed weights: per layer and k-step [16 column tiles of wh | 16 of wl], one
+// linear stream over all layers.
 // Range: fp16 holds |x| < 65504.  Weights are checked when they are packed (azr_nn_set_weights fails loudly); an activation
 // beyond the range would turn into inf -> NaN outputs, which the search counts as rule errors (never silently wrong).
 #include <math.h>
@@ -60,16 +62,10 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 namespace {
 constexpr int NT = 4;                  // 16-channel column tiles per wave (4 waves x 64 channels)
 constexpr int WAVES = 4, THREADS = 256;
-constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;   // 2^11: fp16 has 11 significand bits
-constexpr int STEPS = 144;             // k-steps of a layer: 72 cross-term steps, then 72 main-term steps
-constexpr uint32_t STEP_BYTES = 2 * (uint32_t)KBYTES;            // packed bytes per k-step: wh tiles | wl' tiles
-constexpr uint32_t LAYER_BYTES = 72 * STEP_BYTES;
+constexpr int STEPS = 72;              // k-steps of a layer (9 taps x 8 slices of 32 input channels)
+constexpr uint32_t STEP_BYTES = 2 * (uint32_t)KBYTES;            // packed bytes per k-step: wh tiles | wl tiles
+constexpr uint32_t LAYER_BYTES = STEPS * STEP_BYTES;
 constexpr int STEM_K = 9 * 13, STEM_KS4 = (STEM_K + 3) / 4;      // stem on the 16x16x4 fp32 MFMA: 30 k-steps
-
-// byte offset of k-step f (counted from the current layer's step 0; f >= 144 runs into the next layers) inside the packed stream
-__host__ __device__ constexpr uint32_t step_off(int f) { return (uint32_t)(f / STEPS) * LAYER_BYTES + (uint32_t)((f % STEPS) % 72) * STEP_BYTES; }
-__host__ __device__ constexpr bool step_cross(int f) { return (f % STEPS) < 72; }
-__host__ __device__ constexpr int step_loads(int f) { return step_cross(f) ? 2 * NT : NT; }
 
 template <int NB_>
 struct FX {
@@ -96,11 +92,11 @@ struct FX {
 
 __device__ __forceinline__ f16x8 lds16h(const uint8_t* p) { return *reinterpret_cast<const f16x8*>(p); }
 
-// the pair of an fp32 value: hi = rne16(y), lo' = rne16((y - hi) * 2^11)
+// the pair of an fp32 value: hi = rne16(y), lo = rne16(y - hi)
 __device__ __forceinline__ void split_pair(float y, _Float16& hi, _Float16& lo)
 {
     hi = (_Float16)y;
-    lo = (_Float16)((y - (float)hi) * LO_SCALE);
+    lo = (_Float16)(y - (float)hi);
 }
 
 // layer epilogue for 4 consecutive channels of one board cell: folded BN (fp32 fma), optional shortcut add (fp32), ReLU;
@@ -123,96 +119,86 @@ __device__ __forceinline__ void bn_relu_split(const f32x4& acc, const float4& s,
 
 #define MFMA16(W, A, ACC) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, W), A, ACC, 0, 0, 0)
 
-// One tap (8 k-steps of 32 input channels) of one phase of a 3x3 conv layer for the MT row tiles x 4 column tiles of a wave.
-// PH = 0: cross terms (per tile 8 MFMAs: wh x al', wl' x ah), PH = 1: main term (4 MFMAs: wh x ah).  Everything that depends on
-// the tap and phase — which tiles run, ring slots, stream offsets, wait counts — is a compile-time constant.  The non-MFMA work of
-// a k-step (refill loads of the ring slot the previous k-step freed, LDS fragment reads, next-tap table lookups) is dealt out
-// between the MFMAs as in k_tower_sb.
-template <int NB, int PH, int TAP>
+// One tap (8 k-steps of 32 input channels) of a 3x3 conv layer for the MT row tiles x 4 column tiles of a wave: per tile and k-step
+// 12 MFMAs (wh x ah, wh x al, wl x ah).  Everything that depends on the tap — which tiles run, ring slots, wait counts — is a
+// compile-time constant; `ws` = byte offset of the layer's k-step 0 in the packed stream (the stream is linear over the layers, so the
+// ring's look-ahead simply runs into the next layer).  The non-MFMA work of a k-step (the 8 refill loads of the ring slot the previous
+// k-step freed, the LDS fragment reads, next-tap table lookups) is dealt out between the MFMAs as in k_tower_sb.
+template <int NB, int TAP>
 __device__ __forceinline__ void conv_tap(const uint8_t* bufH, const uint8_t* bufL, const uint8_t* tr_c, uint32_t g16,
-                                         const __amdgpu_buffer_rsrc_t wsrc, uint32_t loff, uint32_t wl, u32x4 (&bq)[FX<NB>::RING][2 * NT],
+                                         const __amdgpu_buffer_rsrc_t wsrc, uint32_t loff, uint32_t ws, u32x4 (&bq)[FX<NB>::RING][2 * NT],
                                          f32x4 (&acc)[FX<NB>::MT][NT], f16x8 (&ah)[FX<NB>::MT], f16x8 (&al)[FX<NB>::MT], uint32_t (&ap)[FX<NB>::MT])
 {
     constexpr int MT = FX<NB>::MT, ZR = FX<NB>::ZR, RING = FX<NB>::RING;
-    constexpr int NTAP = TAP < 8 ? TAP + 1 : (PH == 0 ? 0 : 9);   // the tap that runs next (9 = none: the layer ends)
-    constexpr int NPH = TAP < 8 ? PH : 1;                         // ... and its phase
+    constexpr int NTAP = TAP < 8 ? TAP + 1 : 9;                   // the tap that runs next (9 = none: the layer ends)
     constexpr uint32_t sk = skip_mask<NB>(TAP), skn = skip_mask<NB>(NTAP);
     constexpr int active = MT - __builtin_popcount(sk & ((1u << MT) - 1u));   // tiles that run this tap
-    constexpr int SLOTS = PH == 0 ? 2 * active : active;                       // refill slots of a k-step (MFMA gaps that take a load)
+    constexpr int SLOTS = 2 * active;                                          // refill slots of a k-step (MFMA gaps that take a load)
+    constexpr int NL = 2 * NT;                                                 // refill loads of a k-step
     uint32_t np[MT];
 #pragma unroll
     for (int ks = 0; ks < KS_PER_TAP; ks++) {
-        const int gk = PH * 72 + TAP * KS_PER_TAP + ks;             // k-step inside the layer
+        const int gk = TAP * KS_PER_TAP + ks;                       // k-step inside the layer
         const int cur = gk % RING, ref = (gk + RING - 1) % RING;    // ring slot in use / slot freed by the previous k-step
-        const int fut = gk + RING - 1;                              // the k-step whose fragments go into `ref` now
-        const int nl = step_loads(fut);
-        {   // this k-step's fragments have landed; the loads of the RING - 2 k-steps behind it stay in flight: vmcnt(VM), lgkmcnt /
-            // expcnt untouched (the builtin wants a literal: VM is 8, 12 or 16 and folds after unrolling)
-            static_assert(RING == 4, "the wait counts below are those of a 4-deep ring");
-            const int VM = step_loads(gk + 1) + step_loads(gk + 2);
-            if (VM == 16) __builtin_amdgcn_s_waitcnt(0x0F70 | (16 & 15) | ((16 >> 4) << 14));
-            else if (VM == 12) __builtin_amdgcn_s_waitcnt(0x0F70 | 12);
-            else __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
-        }
+        const uint32_t fut = ws + (uint32_t)(gk + RING - 1) * STEP_BYTES;   // the k-step whose fragments go into `ref` now
+        // this k-step's fragments have landed; the loads of the RING - 2 k-steps behind it stay in flight: vmcnt(16) (6-bit field:
+        // low 4 bits in [3:0], high 2 in [15:14]); lgkmcnt / expcnt untouched
+        static_assert(RING == 4 && NL == 8, "the wait count below is that of a 4-deep ring of 8 loads per k-step");
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (16 & 15) | ((16 >> 4) << 14));
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             if (!((sk >> mt) & 1u)) {
                 const int j = __builtin_popcount(~sk & ((1u << mt) - 1u));   // index among the active tiles
-                // refill load q of the nl goes into gap `slot q` = (q * SLOTS) / nl  (every q lands in [0, SLOTS), also when a short
-                // main-term k-step has fewer gaps than the next layer's cross-term k-step has loads)
+                // refill load q of the 8 goes into gap `slot q` = (q * SLOTS) / NL
 #define REFILL(SLOT)                                                                                                                       \
-    _Pragma("unroll") for (int q = 0; q < nl; q++) if ((SLOT) == (q * SLOTS) / nl)                                                         \
-        bq[ref][q] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, loff + (q & 3) * 1024, (int)(wl + step_off(fut) + (q >> 2) * (uint32_t)KBYTES), 0)
-                if (PH == 0) {
+    _Pragma("unroll") for (int q = 0; q < NL; q++) if ((SLOT) == (q * SLOTS) / NL)                                                         \
+        bq[ref][q] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, loff + (q & 3) * 1024, (int)(fut + (q >> 2) * (uint32_t)KBYTES), 0)
+                MFMA16(bq[cur][0], ah[mt], acc[mt][0]);
+                REFILL(2 * j);
+                __builtin_amdgcn_sched_barrier(0);
+                MFMA16(bq[cur][1], ah[mt], acc[mt][1]);
+                MFMA16(bq[cur][2], ah[mt], acc[mt][2]);
+                MFMA16(bq[cur][3], ah[mt], acc[mt][3]);
 #if FX_DROP != 1
-                    MFMA16(bq[cur][0], al[mt], acc[mt][0]);
+                MFMA16(bq[cur][0], al[mt], acc[mt][0]);
+                MFMA16(bq[cur][1], al[mt], acc[mt][1]);
+                MFMA16(bq[cur][2], al[mt], acc[mt][2]);
+                MFMA16(bq[cur][3], al[mt], acc[mt][3]);
 #endif
-                    REFILL(2 * j);
-                    __builtin_amdgcn_sched_barrier(0);
-#if FX_DROP != 1
-                    MFMA16(bq[cur][1], al[mt], acc[mt][1]);
-                    MFMA16(bq[cur][2], al[mt], acc[mt][2]);
-                    MFMA16(bq[cur][3], al[mt], acc[mt][3]);
-#endif
-                    if (ks < KS_PER_TAP - 1) al[mt] = lds16h(bufL + ap[mt] + (ks + 1) * 64);
-                    __builtin_amdgcn_sched_barrier(0);
+                if (ks < KS_PER_TAP - 1) al[mt] = lds16h(bufL + ap[mt] + (ks + 1) * 64);
+                __builtin_amdgcn_sched_barrier(0);
 #if FX_DROP != 2
-                    MFMA16(bq[cur][4], ah[mt], acc[mt][0]);
+                MFMA16(bq[cur][4], ah[mt], acc[mt][0]);
 #endif
-                    REFILL(2 * j + 1);
-                    __builtin_amdgcn_sched_barrier(0);
+                REFILL(2 * j + 1);
+                __builtin_amdgcn_sched_barrier(0);
 #if FX_DROP != 2
-                    MFMA16(bq[cur][5], ah[mt], acc[mt][1]);
-                    MFMA16(bq[cur][6], ah[mt], acc[mt][2]);
-                    MFMA16(bq[cur][7], ah[mt], acc[mt][3]);
+                MFMA16(bq[cur][5], ah[mt], acc[mt][1]);
+                MFMA16(bq[cur][6], ah[mt], acc[mt][2]);
+                MFMA16(bq[cur][7], ah[mt], acc[mt][3]);
 #endif
-                    if (ks < KS_PER_TAP - 1) ah[mt] = lds16h(bufH + ap[mt] + (ks + 1) * 64);
-                } else {
-                    MFMA16(bq[cur][0], ah[mt], acc[mt][0]);
-                    REFILL(j);
-                    __builtin_amdgcn_sched_barrier(0);
-                    MFMA16(bq[cur][1], ah[mt], acc[mt][1]);
-                    MFMA16(bq[cur][2], ah[mt], acc[mt][2]);
-                    MFMA16(bq[cur][3], ah[mt], acc[mt][3]);
-                    if (ks < KS_PER_TAP - 1) ah[mt] = lds16h(bufH + ap[mt] + (ks + 1) * 64);
-                }
+                if (ks < KS_PER_TAP - 1) ah[mt] = lds16h(bufH + ap[mt] + (ks + 1) * 64);
 #undef REFILL
             }
             // the next tap's source rows: one table byte per tile slot two k-steps before the tap ends, its address arithmetic
             // one k-step later, the first fragments of the next tap in the last k-step
-            if (ks == KS_PER_TAP - 3) { if (!((skn >> mt) & 1u)) np[mt] = (uint32_t)tr_c[NTAP * ZR + mt * 16]; }
-            if (ks == KS_PER_TAP - 2) { if (!((skn >> mt) & 1u)) np[mt] = np[mt] * ROWB + g16; }
-            if (ks == KS_PER_TAP - 1) {
-                if (!((skn >> mt) & 1u)) {
-                    ah[mt] = lds16h(bufH + np[mt]);
-                    if (NPH == 0) al[mt] = lds16h(bufL + np[mt]);
+            if (NTAP < 9) {
+                if (ks == KS_PER_TAP - 3) { if (!((skn >> mt) & 1u)) np[mt] = (uint32_t)tr_c[NTAP * ZR + mt * 16]; }
+                if (ks == KS_PER_TAP - 2) { if (!((skn >> mt) & 1u)) np[mt] = np[mt] * ROWB + g16; }
+                if (ks == KS_PER_TAP - 1) {
+                    if (!((skn >> mt) & 1u)) {
+                        ah[mt] = lds16h(bufH + np[mt]);
+                        al[mt] = lds16h(bufL + np[mt]);
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    if (NTAP < 9) {
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++) ap[mt] = np[mt];
+        for (int mt = 0; mt < MT; mt++) ap[mt] = np[mt];
+    }
 }
 
 template <int NB>
@@ -246,7 +232,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_fx(const uint8_t* __restri
     for (int ks = 0; ks < RING - 1; ks++)
 #pragma unroll
         for (int q = 0; q < 2 * NT; q++)
-            bq[ks][q] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, loff + (q & 3) * 1024, (int)(step_off(ks) + (q >> 2) * (uint32_t)KBYTES), 0);
+            bq[ks][q] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, loff + (q & 3) * 1024, (int)((uint32_t)ks * STEP_BYTES + (q >> 2) * (uint32_t)KBYTES), 0);
 
     // ---- stage the NNInputData images, build the row tables
     for (int i = tid; i < NB * 96; i += THREADS) {
@@ -350,31 +336,17 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_fx(const uint8_t* __restri
                 if (!((sk0 >> mt) & 1u)) { ah[mt] = lds16h(bufH + ap[mt]); al[mt] = lds16h(bufL + ap[mt]); }
             }
         }
-        conv_tap<NB, 0, 0>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
-        conv_tap<NB, 0, 1>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
-        conv_tap<NB, 0, 2>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
-        conv_tap<NB, 0, 3>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
-        conv_tap<NB, 0, 4>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
-        conv_tap<NB, 0, 5>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
-        conv_tap<NB, 0, 6>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
-        conv_tap<NB, 0, 7>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
-        conv_tap<NB, 0, 8>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
-        // the cross terms were accumulated at 2^11 times their weight
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) acc[mt][nt] *= LO_INV;
-        conv_tap<NB, 1, 0>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
-        conv_tap<NB, 1, 1>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
-        conv_tap<NB, 1, 2>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
-        conv_tap<NB, 1, 3>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
+        conv_tap<NB, 0>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
+        conv_tap<NB, 1>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
+        conv_tap<NB, 2>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
+        conv_tap<NB, 3>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
         // this layer's folded BN scale / shift (see the epilogue): requested 40 k-steps ahead of their use, not a whole layer
         const float2 fnext = *reinterpret_cast<const float2*>(fold + 14 + (size_t)L * 2 * NF + 2 * tid);
-        conv_tap<NB, 1, 4>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
-        conv_tap<NB, 1, 5>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
-        conv_tap<NB, 1, 6>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
-        conv_tap<NB, 1, 7>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
-        conv_tap<NB, 1, 8>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
+        conv_tap<NB, 4>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
+        conv_tap<NB, 5>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
+        conv_tap<NB, 6>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
+        conv_tap<NB, 7>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
+        conv_tap<NB, 8>(bufH, bufL, tr_c, g16, wsrc, loff, wl, bq, acc, ah, al, ap);
         wl += LAYER_BYTES;
         // this layer's folded BN scale / shift go through LDS (2 registers per lane over the k-steps instead of 32)
         *reinterpret_cast<float2*>(foldl + 2 * tid) = fnext;
@@ -443,7 +415,7 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_fx(const uint8_t* __restri
             for (int q = 0; q < NF / 8; q++) {
                 const f16x8 hh = h8[q], ll = l8[q];
 #pragma unroll
-                for (int e = 0; e < 8; e++) sacc = fmaf(fmaf((float)ll[e], LO_INV, (float)hh[e]), w[8 * q + e], sacc);
+                for (int e = 0; e < 8; e++) sacc = fmaf((float)hh[e] + (float)ll[e], w[8 * q + e], sacc);
             }
             const float* bnp = ch < 2 ? bnpi : bnv;
             const int nc = ch < 2 ? 2 : 1, kk = ch < 2 ? ch : 0;
@@ -525,9 +497,13 @@ void net_fx_free(azr_engine* h)
 
 // pack the HWIO fp32 kernels of the AZRW vector into fp16 pairs in MFMA operand fragment order:
 // fragment (layer, tap, ks, half, ctile), lane l, element j  <-  pair(s_L * W[tap][ci = ks*32 + 8*(l>>4) + j][co = ctile*16 + (l&15)])
-// s_L = the power of two that brings the layer's largest |w| into [2^13, 2^14): the matrix core flushes fp16 SUBNORMAL operands
-// (|x| < 6.1e-5) to zero, and unscaled Glorot weights of +-0.036 put 0.2 % of a layer's weights there — measured: 1.3e-4 in
-// pi / v at B = 20 against 3e-6 with the scale.  1 / s_L goes into the layer's folded BN scale: powers of two, exact.
+// s_L = the power of two that brings the layer's largest |w| into [2^13, 2^14): the low part of an fp16 pair is worth 11 more bits only
+// while it is a NORMAL fp16 number (>= 6.1e-5), and the low parts of unscaled Glorot weights of +-0.036 (|lo| <= 1.8e-5) are all
+// subnormal: they keep 2^-24 absolute, i.e. 13 - 14 bits of the weight in all — measured: 1.3e-4 in pi / v at B = 20 against 3e-6 with
+// the scale.  (The matrix core does NOT flush subnormal operands: profiles/r03_mfma_round_probe.txt; the loss is the subnormals' own
+// precision.)  With the scale a weight down to 2^-11 of the layer's largest keeps a normal low part.  1 / s_L goes into the layer's
+// folded BN scale: powers of two, exact.  Activations are not scaled: their low parts are subnormal below 2^-3 and then carry 2^-25
+// absolute, the size of rounding the activation to fp32 (header).
 // fold_host = the folded BN table of net_upload (stem scale[7] shift[7]; per conv layer scale[256] shift[256]).
 int net_fx_upload(azr_engine* h, const float* fold_host)
 {
@@ -569,7 +545,7 @@ int net_fx_upload(azr_engine* h, const float* fold_host)
                         for (int j = 0; j < 8; j++) {
                             const float w = W[((size_t)tap * NF + ci0 + j) * NF + co] * sL;
                             const _Float16 hi = (_Float16)w;
-                            const _Float16 lo = (_Float16)((w - (float)hi) * LO_SCALE);
+                            const _Float16 lo = (_Float16)(w - (float)hi);
                             memcpy(dh + j, &hi, 2);
                             memcpy(dl + j, &lo, 2);
                         }
