@@ -278,7 +278,7 @@ constexpr size_t WPACK = (size_t)KC * NF;  // elements per layer, part and view
 // wscale > 0: fp16 PAIRS of wscale * W instead of bf16 parts (p0 = hi, p1 = lo; the forward conv on the fp16 MFMA)
 template <int NP>
 __global__ __launch_bounds__(256) void t_pack_w(const float* __restrict__ flat, int view, uint16_t* __restrict__ p0, uint16_t* __restrict__ p1,
-                                                uint16_t* __restrict__ p2, float wscale = 0.0f)
+                                                uint16_t* __restrict__ p2, float wscale = 0.0f, int* __restrict__ range_flag = nullptr)
 {
     // one thread = one lane's 8 values of one fragment: index = ((kt * 16 + nt) * 64 + lane)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -294,6 +294,9 @@ __global__ __launch_bounds__(256) void t_pack_w(const float* __restrict__ flat, 
                                   : W[((size_t)tap * NF + n) * NF + (c0 + j)];   // ci = n, co = c0 + j
         if (wscale > 0.0f) {
             const float vs = v * wscale;
+            // a weight that leaves the fp16 range (|w| >= 64 at the 2^10 scale) or is not a number would turn into inf / NaN here and
+            // poison the step silently: raise the step's range flag instead (read by the caller behind the epoch)
+            if (!(fabsf(vs) < 65504.0f) && range_flag) atomicOr(range_flag, 1);
             const _Float16 hh = (_Float16)vs, ll = (_Float16)(vs - (float)hh);
             h[j] = __builtin_bit_cast(uint16_t, hh);
             m[j] = __builtin_bit_cast(uint16_t, ll);
@@ -2176,7 +2179,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     auto Wpb = [&](int l) { const size_t o = (size_t)(l - 1) * KC * NF; return Parts{{c->wpb[0] + o, c->wpb[1] + o, nullptr}}; };
     if (sb) {
         const dim3 pg((unsigned)((wn_ / 8 + 255) / 256), 2 * B);
-        hipLaunchKernelGGL((t_pack_w<3>), pg, dim3(256), 0, st, w, 0, c->wpf[0], c->wpf[1], c->wpf[2], f16 ? FWD_WSCALE : 0.0f);
+        hipLaunchKernelGGL((t_pack_w<3>), pg, dim3(256), 0, st, w, 0, c->wpf[0], c->wpf[1], c->wpf[2], f16 ? FWD_WSCALE : 0.0f, c->cur + 3);
         hipLaunchKernelGGL((t_pack_w<2>), pg, dim3(256), 0, st, w, 1, c->wpb[0], c->wpb[1], (uint16_t*)nullptr);
     }
 
@@ -2389,6 +2392,25 @@ int run_step(azr_engine* h, TrainCtx* c)
     return train_step(h, c, c->loss + 2);
 }
 
+// Behind an epoch (or a single step): did a conv weight leave the range of the fp16-pair forward conv (t_pack_w's flag: |w| >= 64, or
+// not a number), or did the losses stop being numbers?  Then the device copy of the weights and the optimiser state are poisoned: the
+// call fails loudly, the weights the handle had before the call (its host AZRW copy) are put back and the optimiser state is dropped.
+int step_health(azr_engine* h, TrainCtx* c, float loss_pi, float loss_v)
+{
+    int flag = 0;
+    HIPCHK(h, hipMemcpyAsync(&flag, c->cur + 3, sizeof flag, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!flag && std::isfinite(loss_pi) && std::isfinite(loss_v)) return AZR_OK;
+    HIPCHK(h, hipMemcpyAsync(h->net.d_flat, h->flat.data(), h->flat.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    azr::train_free(h);
+    h->err = flag ? "azr_nn_train: a conv weight left the range of the fp16-pair forward conv (|w| must stay below 64) or is not a number; "
+                    "the weights from before the call have been restored and the optimiser state dropped"
+                  : "azr_nn_train: the loss is not a number (diverged step); the weights from before the call have been restored and the "
+                    "optimiser state dropped";
+    return AZR_E_INVALID_ARGUMENT;
+}
+
 // after training: device master copy -> host AZRW copy -> refold / repack for inference
 int finish(azr_engine* h)
 {
@@ -2446,14 +2468,15 @@ extern "C" int azr_nn_train_batch(azr_engine* h, const void* rec265_host, int n,
     for (int i = 0; i < n; i++) id[i] = i;
     HIPCHK(h, hipMemcpyAsync(c->perm, id.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
     {
-        const int cur3[3] = {0, (int)c->step, 0};
-        HIPCHK(h, hipMemcpyAsync(c->cur, cur3, sizeof cur3, hipMemcpyHostToDevice, h->stream));
+        const int cur4[4] = {0, (int)c->step, 0, 0};
+        HIPCHK(h, hipMemcpyAsync(c->cur, cur4, sizeof cur4, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     HIPCHK(h, hipMemsetAsync(c->loss + 2, 0, 2 * sizeof(float), h->stream));
     TRY(run_step(h, c));
     float l[2];
     HIPCHK(h, hipMemcpyAsync(l, c->loss, sizeof l, hipMemcpyDeviceToHost, h->stream));
+    TRY(step_health(h, c, l[0], l[1]));
     TRY(finish(h));
     if (loss_pi) *loss_pi = l[0];
     if (loss_v) *loss_v = l[1];
@@ -2501,15 +2524,16 @@ static int train_impl(azr_engine* h, const void* rec265_host, size_t n, int epoc
         std::shuffle(order.begin(), order.end(), eng);  // alphazero_nn.cpp:372 (same libstdc++ algorithm, same engine)
         float l[2] = {NAN, NAN};
         if (batches > 0) {
-            const int cur3[3] = {0, (int)c->step, rank * local_bs};   // minibatch offset, Adam step count, this rank's slice
+            const int cur4[4] = {0, (int)c->step, rank * local_bs, 0};   // minibatch offset, Adam step count, this rank's slice, range flag
             HIPCHK(h, hipMemcpyAsync(c->perm, order.data(), n * sizeof(int), hipMemcpyHostToDevice, h->stream));
             HIPCHK(h, hipMemsetAsync(c->loss + 2, 0, 2 * sizeof(float), h->stream));
-            HIPCHK(h, hipMemcpyAsync(c->cur, cur3, sizeof cur3, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(c->cur, cur4, sizeof cur4, hipMemcpyHostToDevice, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
             for (size_t b = 0; b < batches && rc == AZR_OK; b++) rc = run_step(h, c);
             if (rc) break;
             HIPCHK(h, hipMemcpyAsync(l, c->loss + 2, sizeof l, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
+            rc = step_health(h, c, l[0], l[1]);   // (synchronises the stream)
+            if (rc) { c = nullptr; break; }       // (the training context is gone with the poisoned optimiser state)
             l[0] /= (float)batches;
             l[1] /= (float)batches;
         }

@@ -119,7 +119,11 @@ int azr_nn_predict(azr_engine* h, const void* in88_host, int n, float* pi_host, 
  * src/rng.h:50; NULL = default-seeded), floor(n / batch_size) minibatch steps of the `optimize` op (fp32 forward in
  * training mode, loss, backward, Adam; python/src/build_graph.py:54-103), remainder dropped.  loss_*_host[e] = the
  * epoch averages the reference prints and logs (NaN when n < batch_size).  Adam moments and step count persist on the
- * handle across calls like the TF session's slots; inference weights are refolded / repacked before returning. */
+ * handle across calls like the TF session's slots; inference weights are refolded / repacked before returning.
+ * Range: the forward conv multiplies fp16 pairs of 2^10 w, so a conv weight with |w| >= 64 (or a weight that is not a number) cannot be
+ * represented; that, and a loss that stops being a number, is detected behind every epoch: the call then returns
+ * AZR_E_INVALID_ARGUMENT with the reason in azr_last_error, the handle's weights are those from before the call and its optimiser
+ * state is dropped (the reference's TensorFlow step would carry the NaNs on silently). */
 int azr_nn_train(azr_engine* h, const void* rec265_host, size_t n, int epochs, int batch_size,
                  uint32_t* shuffle_rng_state, float* loss_pi_host, float* loss_v_host);
 /* Data-parallel AlphaZeroNN::train: the same epochs / shuffles / minibatches, every minibatch split over `world` ranks

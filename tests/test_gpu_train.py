@@ -321,3 +321,31 @@ def test_training_reduces_loss_on_fixed_batch():
     # the policy targets are high-entropy random distributions, so CE has a floor near their entropy
     assert last[0] < first[0] - 0.3 and last[1] < 0.6 * first[1], (first, last)
     eng.close()
+
+
+def test_weight_outside_the_fp16_pair_range_fails_loudly():
+    """the training forward conv runs on fp16 pairs of 2^10 w; a conv weight with |w| >= 64 would become inf and the step's
+    NaNs would spread silently.  The step detects it (and a loss that is not a number): azr_nn_train returns AZR_E_INVALID_ARGUMENT,
+    the handle keeps the weights it had before the call, inference still works, and a later call with sane weights trains again."""
+    P = pkg()
+    blocks, bs = 1, 32
+    flat = T.make_net_flat(blocks, seed=3)
+    rec = records(2 * bs, seed=9)
+    eng = P.Engine(8, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64)
+    bad = flat.copy()
+    bad[9 * 13 * 256 + 28 + 1000] = 70.0          # one tower conv weight beyond 64
+    eng.set_weights(bad)
+    with pytest.raises(P.AzrError) as ei:
+        eng.train(rec, 1, batch_size=bs, rng_state=5)
+    assert ei.value.code == 1 and "fp16-pair" in str(ei.value)
+    assert (eng.get_weights().view(np.uint32) == bad.view(np.uint32)).all()   # nothing half-trained was left behind
+    pi, v = eng.predict(rec[:4, 1:89].copy())
+    assert np.isfinite(pi).all() and np.isfinite(v).all()
+    eng.set_weights(flat)
+    hist, _ = eng.train(rec, 1, batch_size=bs, rng_state=5)
+    assert np.isfinite(hist[0][0]) and np.isfinite(hist[0][1])
+    ref = P.Engine(8, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64)
+    ref.set_weights(flat)
+    hist2, _ = ref.train(rec, 1, batch_size=bs, rng_state=5)
+    assert hist == hist2 and (eng.get_weights().view(np.uint32) == ref.get_weights().view(np.uint32)).all()   # the optimiser state started afresh
+    eng.close(); ref.close()

@@ -28,7 +28,7 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rng = np.random.default_rng(100 + rank)
-    n = 5 + 7 * rank  # ragged counts, rank 0 smaller than rank 1
+    n = 0 if (world > 2 and rank == 5) else 5 + 7 * rank  # ragged counts, rank 0 smaller than rank 1; at world 8 one rank has nothing
     recs = torch.from_numpy(rng.integers(0, 256, (n, 265), dtype=np.uint8))
     allr = shard.gather_records(recs, dist)
     empty = shard.gather_records(torch.zeros((0, 265), dtype=torch.uint8) if rank == 0 else recs, dist)
@@ -61,6 +61,29 @@ def test_gather_records_world2_gloo():
         assert res[r][4] == {"simulations": 30, "games_finished": 1}
     # seed ranges of different ranks cannot collide for < 2^24 games per slot-stream
     assert res[1][5] - res[0][5] == 1 << 24
+
+
+def test_gather_records_world8_ragged_gloo():
+    """configs[3] / configs[4] at their real rank count (on the CPU, gloo): 8 ragged record counts — one rank contributes none —
+    gathered in rank order on every rank, counters summed, rank 0's weight vector broadcast, 8 disjoint seed ranges"""
+    world = 8
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    want = np.concatenate([res[r][1] for r in range(world)])
+    assert len(want) == sum(5 + 7 * r for r in range(world) if r != 5) and len(res[5][1]) == 0
+    for r in range(world):
+        assert res[r][2].shape == want.shape and (res[r][2] == want).all()
+        assert res[r][4] == {"simulations": 10 * 36, "games_finished": 28}
+    seeds = [res[r][5] for r in range(world)]
+    assert all(b - a == 1 << 24 for a, b in zip(seeds, seeds[1:]))
 
 
 def test_split_count_covers_the_total():
