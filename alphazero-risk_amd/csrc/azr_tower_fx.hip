@@ -388,7 +388,13 @@ __global__ __launch_bounds__(THREADS, 1) void k_tower_fx(const uint8_t* __restri
     }
 
     // ---- both heads (build_graph.py:76-90) on the reconstructed fp32 activations: the fma chains of k_heads (azr_net.hip)
+    // (The thread index goes through an opaque move first: left alone, the compiler computes the heads' thread-dependent addresses
+    //  ahead of the layer loop and carries them across it in registers the loop needs — three of them ended in scratch, written once
+    //  and read once per thread: 1.5 MB of the launch's 1.7 MB of HBM writes.)
     {
+        int tid_h = threadIdx.x;
+        asm volatile("" : "+v"(tid_h));
+        const int tid = tid_h, lane = tid & 63, wave = tid >> 6;
         const float* wpi = hp;              // [256][2]
         const float* bnpi = wpi + NF * 2;   // g[2] b[2] m[2] v[2]
         const float* wd = bnpi + 8;         // [84][43]
