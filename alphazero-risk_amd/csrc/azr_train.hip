@@ -1567,6 +1567,37 @@ __global__ __launch_bounds__(1024) void t_bn_bwd_finalize(const double* __restri
     }
 }
 
+// Two small kernels of the backward chain in ONE launch: the slice sum of layer l + 1's weight gradient (out[i] = sum_z part[z][i],
+// the job of t_sum_slices) and stage 2 of layer l's batch-norm backward (t_bn_bwd_finalize<false>, blocks 0 - 7).  They are neighbours in
+// the stream and independent of each other — the finalize reads the block partials the backward-data conv of layer l + 1 left, the
+// slice sum what that layer's weight-gradient kernel left — so one launch saves a kernel boundary (~3 us on the device) and hides the
+// 5-us finalize under the 10-us sum: ~8 us per layer.
+__global__ __launch_bounds__(1024) void t_sum_slices_fin(const float* __restrict__ wpart, int nz, size_t n, float* __restrict__ out,
+                                                         const double* __restrict__ part, int R, float* __restrict__ gbn, float* __restrict__ sums,
+                                                         float gscale)
+{
+    if (blockIdx.x < 8) {
+        __shared__ double sh[1024];
+        const int c = blockIdx.x * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;
+        double s = 0.0, sx = 0.0;
+        for (int b = q; b < R; b += 32) { s += part[((size_t)b * 2 + 0) * NF + c]; sx += part[((size_t)b * 2 + 1) * NF + c]; }
+        s = reduce_q32(s, sh);
+        sx = reduce_q32(sx, sh);
+        if (q == 0) {
+            gbn[c] = (float)sx * gscale;
+            gbn[NF + c] = (float)s * gscale;
+            sums[c] = (float)s;
+            sums[NF + c] = (float)sx;
+        }
+        return;
+    }
+    const size_t i = (size_t)(blockIdx.x - 8) * 1024 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int z = 0; z < nz; z++) s += wpart[(size_t)z * n + i];
+    out[i] = s;
+}
+
 // backward stage 3: dY = gamma * istd * (dz - sum(dz)/n - xhat * sum(dz xhat)/n); dZ (optional) = dz for the shortcut
 template <bool STEM>
 __global__ __launch_bounds__(256) void t_bn_bwd_apply(const float* __restrict__ dOut, const float* __restrict__ Apost,
@@ -2270,6 +2301,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
     //  block partials are then already in c->part, `fused_parts` blocks of them)
     int fused_parts = 0, side_used = 0;
     const bool fuse = sb && g_fuse_bwd;
+    float* pending_sum = nullptr;   // the slice sum of the layer above is launched together with this layer's BN-backward stage 2 (t_sum_slices_fin)
     for (int l = c->L - 1; l >= 1; l--) {
         // gradient w.r.t. this layer's post-activation output: G for the second conv of a block, DT for the first
         const bool second = (l % 2 == 0);
@@ -2283,7 +2315,14 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
             hipLaunchKernelGGL(t_parts_sum, dim3(2), dim3(256), 0, st, c->part, Rl, 2, c->red);
             TRY(dp_allreduce(h, c, c->red, (size_t)2 * NF, 1));
         }
-        hipLaunchKernelGGL((t_bn_bwd_finalize<false>), dim3(8), dim3(1024), 0, st, dp ? c->red : c->part, dp ? 1 : Rl, gbn, c->sums, gscale);
+        if (pending_sum && !dp && fused_parts) {
+            hipLaunchKernelGGL(t_sum_slices_fin, dim3(8 + (unsigned)((wn + 1023) / 1024)), dim3(1024), 0, st, c->wpart, c->wg_slices, wn, pending_sum, c->part,
+                               Rl, gbn, c->sums, gscale);
+            pending_sum = nullptr;
+        } else {
+            if (pending_sum) { hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, c->wg_slices, wn, pending_sum); pending_sum = nullptr; }
+            hipLaunchKernelGGL((t_bn_bwd_finalize<false>), dim3(8), dim3(1024), 0, st, dp ? c->red : c->part, dp ? 1 : Rl, gbn, c->sums, gscale);
+        }
         float* dIn = second ? c->DT : c->G;
         const Parts apP{{Ap(l - 1).p[0], Ap(l - 1).p[1], nullptr}};
         if (fuse && g_fuse_apply) {
@@ -2317,7 +2356,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
                             // side stream 11.16 ms per step, only its slice sums there 11.28, one stream 11.1 — a cross-stream edge costs the
                             // chain a barrier packet per layer, about what hiding the 10-us slice sum saves.)
                 hipLaunchKernelGGL(t_wgrad_rs, dim3(64 * c->wg_slices), dim3(64), Wg::LDS_BYTES, st, apP, dyP, c->wpart, M, c->wg_slices, c->wg_rows);
-                hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, c->wg_slices, wn, Gl(l));
+                pending_sum = Gl(l);   // summed by the next layer's launch (t_sum_slices_fin), or behind the loop
                 continue;
             }
             // small batches (a rank's share of a data-parallel minibatch): the chain's kernels leave most of the chip idle, the branch runs beside them
@@ -2359,6 +2398,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         gemm<false, true, 64, 2, 3>(st, c->dY, KC, Wl(l), NF, dIn, NF, M, NF, KC);
         if (!second) hipLaunchKernelGGL(t_add, dim3(g4), dim3(256), 0, st, dIn, c->DS, act / 4);  // + shortcut gradient
     }
+    if (pending_sum) hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, c->wg_slices, wn, pending_sum);
     // the weight-gradient branch joins: the stem below reuses its split-K buffer, and the gradient vector is complete behind it
     for (int q = 0; q < 2; q++) if ((side_used >> q) & 1) HIPCHK(h, hipStreamWaitEvent(st, c->ev_wg[q], 0));
     {   // stem: parameters only
