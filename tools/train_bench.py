@@ -13,6 +13,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 P = importlib.import_module("alphazero-risk_amd")
+if os.environ.get("AZR_EXP_LIB"):   # a timing-experiment build of the same sources (never the product library)
+    P.binding.lib_path = lambda test_hooks=False: os.environ["AZR_EXP_LIB"]
 
 
 def main():
