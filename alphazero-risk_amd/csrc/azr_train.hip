@@ -234,8 +234,31 @@ __device__ __forceinline__ uint32_t bf_rne_bits(float f)
     const uint32_t u = __float_as_uint(f);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
+// two floats -> two bf16 (round to nearest even) packed low | high: ONE v_cvt_pk_bf16_f32 where bf_rne_bits spends three integer
+// operations per value and two more to pack — the same bits for every finite input (the staging paths of the fused convs run this for
+// every element of every layer: profiles/r04_train_step.txt)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ uint32_t bf_rne_pk(float a, float b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+// hi and mid bf16 parts of a pair of floats (hi = rne(v), mid = rne(v - hi)), packed
+__device__ __forceinline__ void bf_split2(float a, float b, uint32_t& hi, uint32_t& mid)
+{
+    hi = bf_rne_pk(a, b);
+    mid = bf_rne_pk(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
 __device__ __forceinline__ void split_store4(const float (&v)[4], size_t i4, uint16_t* p0, uint16_t* p1, uint16_t* p2)
 {
+    if (!p2) {   // the two leading parts only (every caller on the step's hot path)
+        uint32_t h01, m01, h23, m23;
+        bf_split2(v[0], v[1], h01, m01);
+        bf_split2(v[2], v[3], h23, m23);
+        reinterpret_cast<uint2*>(p0)[i4] = make_uint2(h01, h23);
+        reinterpret_cast<uint2*>(p1)[i4] = make_uint2(m01, m23);
+        return;
+    }
     uint32_t h[4], m[4], l[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -246,7 +269,7 @@ __device__ __forceinline__ void split_store4(const float (&v)[4], size_t i4, uin
     }
     reinterpret_cast<uint2*>(p0)[i4] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
     reinterpret_cast<uint2*>(p1)[i4] = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
-    if (p2) reinterpret_cast<uint2*>(p2)[i4] = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    reinterpret_cast<uint2*>(p2)[i4] = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
 }
 
 // the fp16 pair of 4 consecutive values: hi = rne16(v), lo = rne16(v - hi) (unscaled: the matrix core takes fp16 subnormals),
@@ -556,11 +579,13 @@ __global__ __launch_bounds__(256, 1) void t_conv_rs(Parts A, Parts Bp, float* __
                         const float v = g4[j] * ((xa[j] - m4[j]) * i4[j]) + q4[j] + xb[j];
                         o[j] = v > 0.0f ? v : 0.0f;
                     }
-                    _Float16 h[4], l[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { h[j] = (_Float16)o[j]; l[j] = (_Float16)(o[j] - (float)h[j]); }
-                    hi = make_uint2(__builtin_bit_cast(uint32_t, f16x2_t{h[0], h[1]}), __builtin_bit_cast(uint32_t, f16x2_t{h[2], h[3]}));
-                    lo = make_uint2(__builtin_bit_cast(uint32_t, f16x2_t{l[0], l[1]}), __builtin_bit_cast(uint32_t, f16x2_t{l[2], l[3]}));
+                    {   // the fp16 pair, two values per conversion (v_cvt_pk_f16_f32, RNE: the bits of the scalar conversions)
+                        const f16x2_t h01 = __builtin_convertvector(f32x2_t{o[0], o[1]}, f16x2_t), h23 = __builtin_convertvector(f32x2_t{o[2], o[3]}, f16x2_t);
+                        const f16x2_t l01 = __builtin_convertvector(f32x2_t{o[0] - (float)h01[0], o[1] - (float)h01[1]}, f16x2_t);
+                        const f16x2_t l23 = __builtin_convertvector(f32x2_t{o[2] - (float)h23[0], o[3] - (float)h23[1]}, f16x2_t);
+                        hi = make_uint2(__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23));
+                        lo = make_uint2(__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23));
+                    }
                     if (uok[i]) {
                         *reinterpret_cast<float4*>(Pf.O + goff[i] + kc * 32) = make_float4(o[0], o[1], o[2], o[3]);
                         split_store4(o, (goff[i] + kc * 32) / 4, Pf.p0, Pf.p1, nullptr);
@@ -577,14 +602,8 @@ __global__ __launch_bounds__(256, 1) void t_conv_rs(Parts A, Parts Bp, float* __
                         z[j] = dz;
                         o[j] = g4[j] * i4[j] * (dz - q4[j] - xh * t4[j]);
                     }
-                    uint32_t h[4], m[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        h[j] = bf_rne_bits(o[j]);
-                        m[j] = bf_rne_bits(o[j] - __uint_as_float(h[j] << 16));
-                    }
-                    hi = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                    lo = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+                    bf_split2(o[0], o[1], hi.x, lo.x);
+                    bf_split2(o[2], o[3], hi.y, lo.y);
                     if (uok[i]) {
                         const size_t i4x = (goff[i] + kc * 32) / 4;
                         reinterpret_cast<uint2*>(Pf.p0)[i4x] = hi;
@@ -862,11 +881,13 @@ __global__ __launch_bounds__(256, 1) void t_conv_q(Parts A, Parts Bp, float* __r
                         const float v = g4[j] * ((xa[j] - m4[j]) * i4[j]) + q4[j] + xb[j];
                         o[j] = v > 0.0f ? v : 0.0f;
                     }
-                    _Float16 h[4], l[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { h[j] = (_Float16)o[j]; l[j] = (_Float16)(o[j] - (float)h[j]); }
-                    hi = make_uint2(__builtin_bit_cast(uint32_t, f16x2_t{h[0], h[1]}), __builtin_bit_cast(uint32_t, f16x2_t{h[2], h[3]}));
-                    lo = make_uint2(__builtin_bit_cast(uint32_t, f16x2_t{l[0], l[1]}), __builtin_bit_cast(uint32_t, f16x2_t{l[2], l[3]}));
+                    {   // the fp16 pair, two values per conversion (v_cvt_pk_f16_f32, RNE: the bits of the scalar conversions)
+                        const f16x2_t h01 = __builtin_convertvector(f32x2_t{o[0], o[1]}, f16x2_t), h23 = __builtin_convertvector(f32x2_t{o[2], o[3]}, f16x2_t);
+                        const f16x2_t l01 = __builtin_convertvector(f32x2_t{o[0] - (float)h01[0], o[1] - (float)h01[1]}, f16x2_t);
+                        const f16x2_t l23 = __builtin_convertvector(f32x2_t{o[2] - (float)h23[0], o[3] - (float)h23[1]}, f16x2_t);
+                        hi = make_uint2(__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23));
+                        lo = make_uint2(__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23));
+                    }
                     if (cq == 0) {
                         *reinterpret_cast<float4*>(Pf.O + go) = make_float4(o[0], o[1], o[2], o[3]);
                         split_store4(o, go / 4, Pf.p0, Pf.p1, nullptr);
@@ -884,14 +905,8 @@ __global__ __launch_bounds__(256, 1) void t_conv_q(Parts A, Parts Bp, float* __r
                         z[j] = dz;
                         o[j] = g4[j] * i4[j] * (dz - q4[j] - xh * t4[j]);
                     }
-                    uint32_t h[4], m[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        h[j] = bf_rne_bits(o[j]);
-                        m[j] = bf_rne_bits(o[j] - __uint_as_float(h[j] << 16));
-                    }
-                    hi = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                    lo = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+                    bf_split2(o[0], o[1], hi.x, lo.x);
+                    bf_split2(o[2], o[3], hi.y, lo.y);
                     if (cq == 0) {
                         reinterpret_cast<uint2*>(Pf.p0)[go / 4] = hi;
                         reinterpret_cast<uint2*>(Pf.p1)[go / 4] = lo;
