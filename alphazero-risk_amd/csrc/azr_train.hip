@@ -726,28 +726,50 @@ __global__ __launch_bounds__(256, 1) void t_conv_rs(Parts A, Parts Bp, float* __
 #pragma unroll
             for (int e = 0; e < 4; e++) s[nt][e] = sx[nt][e] = 0.0;
         }
+        // EPG row tiles at a time: ALL their loads (shortcut gradient, post-activation, pre-BN output of layer l - 1 at the output
+        // coordinates: up to 24 x 16 bytes per lane) are issued before the first is used — taken one tile at a time, every tile paid
+        // its own round trip to memory (the weight ring and the fragment registers are dead here: the registers are free).
+        // The sums run over the tiles in the same order as before: same bits.
+        constexpr int EPG = 3;
+        static_assert(MT % EPG == 0, "tiles per epilogue group");
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-            const int ci = rowcell[mt * 16 + c];
-            const bool valid = !(ci == 0xffff || (ci >> 8) >= nbv);
-            const size_t o = (size_t)(m0 + (valid ? (ci >> 8) * NPOS + (ci & 15) * 6 + ((ci >> 4) & 15) : 0)) * NF + wave * 64 + g * 4;
-            if (valid) {
+        for (int m2 = 0; m2 < MT; m2 += EPG) {
+            size_t o[EPG];
+            bool valid[EPG];
+            float4 d4[EPG][NT], a4[EPG][NT], y4[EPG][NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; nt++) {
-                    float4 v = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
-                    if (F.DS) {
-                        const float4 d = *reinterpret_cast<const float4*>(F.DS + o + nt * 16);
-                        v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+            for (int u = 0; u < EPG; u++) {
+                const int mt = m2 + u;
+                const int ci = rowcell[mt * 16 + c];
+                valid[u] = !(ci == 0xffff || (ci >> 8) >= nbv);
+                o[u] = (size_t)(m0 + (valid[u] ? (ci >> 8) * NPOS + (ci & 15) * 6 + ((ci >> 4) & 15) : 0)) * NF + wave * 64 + g * 4;
+                if (valid[u]) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) {
+                        d4[u][nt] = F.DS ? *reinterpret_cast<const float4*>(F.DS + o[u] + nt * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        a4[u][nt] = *reinterpret_cast<const float4*>(F.Apost + o[u] + nt * 16);
+                        y4[u][nt] = *reinterpret_cast<const float4*>(F.Y + o[u] + nt * 16);
                     }
-                    *reinterpret_cast<float4*>(C + o + nt * 16) = v;
-                    const float4 a4 = *reinterpret_cast<const float4*>(F.Apost + o + nt * 16), y4 = *reinterpret_cast<const float4*>(F.Y + o + nt * 16);
-                    const float vv[4] = {v.x, v.y, v.z, v.w}, aa[4] = {a4.x, a4.y, a4.z, a4.w}, yy[4] = {y4.x, y4.y, y4.z, y4.w};
-                    const float mm[4] = {mu[nt].x, mu[nt].y, mu[nt].z, mu[nt].w}, ii[4] = {is[nt].x, is[nt].y, is[nt].z, is[nt].w};
+                }
+            }
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const float dz = aa[e] > 0.0f ? vv[e] : 0.0f;
-                        s[nt][e] += (double)dz;
-                        sx[nt][e] += (double)dz * (double)((yy[e] - mm[e]) * ii[e]);
+            for (int u = 0; u < EPG; u++) {
+                const int mt = m2 + u;
+                if (valid[u]) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) {
+                        float4 v = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+                        if (F.DS) { v.x += d4[u][nt].x; v.y += d4[u][nt].y; v.z += d4[u][nt].z; v.w += d4[u][nt].w; }
+                        *reinterpret_cast<float4*>(C + o[u] + nt * 16) = v;
+                        const float vv[4] = {v.x, v.y, v.z, v.w}, aa[4] = {a4[u][nt].x, a4[u][nt].y, a4[u][nt].z, a4[u][nt].w},
+                                    yy[4] = {y4[u][nt].x, y4[u][nt].y, y4[u][nt].z, y4[u][nt].w};
+                        const float mm[4] = {mu[nt].x, mu[nt].y, mu[nt].z, mu[nt].w}, ii[4] = {is[nt].x, is[nt].y, is[nt].z, is[nt].w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const float dz = aa[e] > 0.0f ? vv[e] : 0.0f;
+                            s[nt][e] += (double)dz;
+                            sx[nt][e] += (double)dz * (double)((yy[e] - mm[e]) * ii[e]);
+                        }
                     }
                 }
             }
