@@ -726,8 +726,12 @@ __global__ __launch_bounds__(64) void k_arena_step(Dev E)
             const uint32_t w = kind == 3 ? 1u : 0u;   // which AlphaZeroPlayer: its tree and its network
             const Tree& tt = w ? t2 : t;
             if (w) swap_tree_ctl(c, x2);
-            if (!c.turn_started) { tree_trim(tt, c); c.turn_started = 1; }   // the player's own trimNodes
-            if (!c.search_active) { tree_trim(tt, c); c.sims_done = 0; c.sims_started = 0; c.search_active = 1; }  // simulate -> setRootState
+            // the player's own trimNodes at the start of a turn, setRootState's at the start of every search: at a turn's first decision
+            // both run back to back, which leaves an empty tree (tree_trim_twice)
+            if (!c.turn_started && !c.search_active) tree_trim_twice(tt, c);
+            else if (!c.turn_started || !c.search_active) tree_trim(tt, c);
+            c.turn_started = 1;
+            if (!c.search_active) { c.sims_done = 0; c.sims_started = 0; c.search_active = 1; }
             c.search_tree = w;
             c.rng = root.rng;
             uint32_t err = 0;

@@ -219,6 +219,24 @@ __device__ __forceinline__ void tree_trim(const Tree& t, Ctl& c)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
+// Two trimNodes in a row with no search between them — AlphaZeroPlayer::takeTurn's own trim followed by setRootState's at the first
+// decision of a turn (alphazero_player.cpp:5, alphazero_mcts.cpp:255-270) — keep NOTHING: the first leaves the survivors' stamps as
+// they were, the second finds no node stamped since.  The state two tree_trim calls leave behind, written directly: empty table, every
+// slot below the high-water mark free in ascending order, the stamp counter two further — without the first trim's scan, its
+// survivors' re-insertion and the second clearing of the table.
+__device__ __forceinline__ void tree_trim_twice(const Tree& t, Ctl& c)
+{
+    c.search_id += 2;
+    for (int i = (int)lane_id(); i < t.H; i += 64) t.table[i] = 0;
+    const uint32_t hw = c.hiwater;
+    for (uint32_t i = lane_id(); i < hw; i += 64) {
+        t.freel[i] = (uint16_t)i;
+        t.touch[i] = 0;
+    }
+    c.nfree = hw;
+    wave_mem_sync();
+}
+
 // libstdc++ unordered_map<LandIndex,...> iteration order (alphazero_mcts.cpp:78): returns the key
 // of `ties` that comes first when the set bits of `valid` were inserted in ascending order.  Emulates
 // _Hashtable::_M_insert_bucket_begin / _M_rehash_aux with the prime policy 13 -> 29 -> 59.  Executed by lane 0

@@ -21,13 +21,14 @@ def main():
     ap.add_argument("--sims", type=int, default=100)
     ap.add_argument("--threads", type=int, default=2)
     ap.add_argument("--blocks", type=int, default=20)
+    ap.add_argument("--pair-halves", type=int, default=1, help="1: a mirrored pair's two games at the same time on two slots; 0: one after the other on one slot")
     a = ap.parse_args()
     new = P.Engine(a.slots, blocks=a.blocks, sims=a.sims, dtype=P.NET_BF16, threads=a.threads)
     old = P.Engine(a.slots, blocks=a.blocks, sims=a.sims, dtype=P.NET_BF16, threads=a.threads)
     new.init_random(1)
     old.init_random(2)
     new.arena_set_opponent(old)
-    new.arena_start(P.PLAYER_ALPHAZERO, P.PLAYER_ALPHAZERO_B, a.games, 0, True, 20260001)
+    new.arena_start(P.PLAYER_ALPHAZERO, P.PLAYER_ALPHAZERO_B, a.games, 0, P.MIRROR_CONCURRENT if a.pair_halves else P.MIRROR_SEQUENTIAL, 20260001)
     t0 = time.time()
     while not new.arena_run(256):
         pass
