@@ -6,6 +6,6 @@ for v in ${VARIANTS:-product nostash noepi both}; do
 import csv
 rows=list(csv.DictReader(open("gpurun_out/prof_train_abl_$v/kernel_stats.csv")))
 for r in rows:
-    if "t_conv_rs" in r["Name"] or "t_wgrad" in r["Name"]: print(r["Name"][28:62], r["Calls"], round(float(r["AverageNs"])/1e3,1))
+    if "t_conv" in r["Name"] or "t_wgrad" in r["Name"]: print(r["Name"][28:62], r["Calls"], round(float(r["AverageNs"])/1e3,1))
 PY
 done
