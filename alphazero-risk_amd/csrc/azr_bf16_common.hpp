@@ -115,6 +115,7 @@ struct Bf16Net {
     uint16_t* sc_ex = nullptr;        // split-channel tower: the exchange images [2 parities][128 pairs][96 rows][256] bf16
     unsigned* sc_counters = nullptr;  // ... the pairs' arrival counters and XCC words
     unsigned sc_spin_limit = 0;       // ... polls of a hand-off before it gives up (a constant in the product library; a test hook otherwise)
+    unsigned sc_serial = 0, sc_tag = 0;  // ... launches so far; (serial << 2) of the last one = what its give-up word is compared with
     int sc_force_wt = 0;              // ... test hook: never the plain-store form of a same-XCD pair
 };
 // words of sc_counters behind the per-pair words: the running launch's give-up word (raised by a hand-off that ran out of polls; the
@@ -129,6 +130,7 @@ int tower_sb_launch(azr_engine* h, int nb, int wgs, const uint8_t* d_in88, int i
 // azr_tower_sc.hip
 int tower_sc_init(azr_engine* h);
 void tower_sc_free(azr_engine* h);
-int tower_sc_launch(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st);
+int tower_sc_launch(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st,
+                    const int* n_dev = nullptr, const int* n_other = nullptr);
 int tower_sc_fallbacks(azr_engine* h, unsigned long long* out);
 }  // namespace azr

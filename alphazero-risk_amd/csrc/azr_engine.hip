@@ -603,6 +603,7 @@ __global__ __launch_bounds__(64) void k_arena_step(Dev E)
 {
     __shared__ int8_t scratch[128];
     const int g = blockIdx.x;
+    if (E.lc_zero >= 0 && g == 0 && threadIdx.x < 2) E.leaf_count[E.lc_zero + threadIdx.x] = 0;   // the next pass's counts (the last readers are done)
     Ctl c;
     ctl_load(c, &E.ctl[g]);
     if (c.mode != 3 || c.arena_state == 2) return;
@@ -779,7 +780,7 @@ __global__ __launch_bounds__(64) void k_arena_step(Dev E)
     if (c.pending) {
         const uint32_t tree = two ? c.search_tree : 0u;
         int base = 0;
-        if (lane_id() == 0) base = atomicAdd(&E.leaf_count[tree], (int)__builtin_popcount(c.pending));   // one atomic per slot
+        if (lane_id() == 0) base = atomicAdd(&E.leaf_count[E.lc_base + tree], (int)__builtin_popcount(c.pending));   // one atomic per slot
         base = (int)rfl((uint32_t)base);
         const uint32_t l = lane_id();
         if (l < (uint32_t)E.T && ((c.pending >> l) & 1u))
@@ -1021,7 +1022,8 @@ static int engine_init(azr_engine* h, const azr_settings* s)
     HIPCHK(h, dmalloc(&d.arena_taken, 1));
     HIPCHK(h, dmalloc(&d.sp_started, 1));
     HIPCHK(h, dmalloc(&d.leaf_list, 2 * GT));      // leaf slots waiting for net A / net B (two-net arena; self-play tail uses [0])
-    HIPCHK(h, dmalloc(&d.leaf_count, (size_t)2));
+    HIPCHK(h, dmalloc(&d.leaf_count, (size_t)4));
+    d.lc_base = 0; d.lc_zero = -1;
     HIPCHK(h, dmalloc(&d.arena_res, 8));
     HIPCHK(h, dmalloc(&d.prev_start, G * GREC));
     HIPCHK(h, dmalloc(&d.script, G * 2 * 32));
@@ -1083,6 +1085,7 @@ extern "C" int azr_engine_destroy(azr_engine* h)
     }
 #endif
     if (h->arena_ev) hipEventDestroy(h->arena_ev);
+    if (h->arena_ev2) hipEventDestroy(h->arena_ev2);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return AZR_OK;
@@ -1585,6 +1588,8 @@ extern "C" int azr_arena_start(azr_engine* h, int player1, int player2, int game
     d.arena_mirror = mirror_games; d.base_seed = base_seed;
     h->mode = 3;
     HIPCHK(h, hipMemsetAsync(d.arena_taken, 0, sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(d.leaf_count, 0, 4 * sizeof(int), h->stream));
+    h->arena_pass = 0;
     HIPCHK(h, hipMemsetAsync(d.arena_res, 0, 8 * sizeof(int), h->stream));
     HIPCHK(h, hipMemsetAsync(d.counters, 0, (size_t)d.G * sizeof(Counters), h->stream));
     HIPCHK(h, hipMemsetAsync(d.alog_status, 0, (size_t)d.G * ALOG, h->stream));
@@ -1598,8 +1603,48 @@ extern "C" int azr_arena_run(azr_engine* h, int passes, int* finished_out)
     ENTER(h);
     if (h->mode != 3) { h->err = "azr_arena_run: call azr_arena_start first"; return AZR_E_STATE; }
     const bool needs_net = h->d.kind0 == AZR_PLAYER_ALPHAZERO || h->d.kind1 == AZR_PLAYER_ALPHAZERO;
+    const int GT = h->d.G * h->d.T;
+    // Up to 256 waiting leaves on the 16-bit towers: the net launches read the tree step's leaf counts from device memory themselves
+    // (net_forward_counted), so a pass is queued without a read-back and the host looks at the slots' states once per CHUNK passes —
+    // the passes of a slot that went idle meanwhile end at their first instruction.  (AZR_ARENA_COUNTED=0, test build: the read-back form.)
+    // (At most min(slots, games) slots ever play: an engine of 512 slots that plays 100 compare games has at most 200 leaves waiting.)
+    const int NB_MAX = std::min(h->d.G, std::max(1, h->d.arena_total)) * h->d.T;
+    const bool counted = hook_env_int("AZR_ARENA_COUNTED", 1) != 0 && net_forward_counted_ok(h, NB_MAX) &&
+                         (!h->d.nodes2 || net_forward_counted_ok(h->opponent, NB_MAX));
+    if (counted && (needs_net || h->d.nodes2)) {
+        constexpr int CHUNK = 16;
+        if (!h->arena_ev) HIPCHK(h, hipEventCreateWithFlags(&h->arena_ev, hipEventDisableTiming));
+        if (!h->arena_ev2) HIPCHK(h, hipEventCreateWithFlags(&h->arena_ev2, hipEventDisableTiming));
+        std::vector<uint32_t> st0(h->d.G);
+        for (int p = 0; p < passes; p++) {
+            // the counts of this pass go to row (pass & 1) of leaf_count — zero since the pass before the last (or azr_arena_start) — and the
+            // step zeroes the other row for the next pass: no memset between a pass's launches either
+            const int row = 2 * (int)(h->arena_pass++ & 1u);
+            Dev e = h->d;
+            e.lc_base = row; e.lc_zero = 2 - row;
+            LAUNCH(h, k_arena_step, e);
+            const int* cnt_dev = h->d.leaf_count + row;
+            const bool beside = h->d.nodes2 && h->opponent != h;   // two launches on two streams (one handle on both sides: one stream, one after the other)
+            if (h->d.nodes2) {   // the opponent's net on the opponent's stream, side by side with this one's: after the tree step, before the next
+                HIPCHK(h, hipEventRecord(h->arena_ev2, h->stream));
+                HIPCHK(h, hipStreamWaitEvent(h->opponent->stream, h->arena_ev2, 0));
+                int rc = net_forward_counted(h->opponent, h->d.leaf_in, LEAF_STRIDE, NB_MAX, cnt_dev + 1, beside ? cnt_dev : nullptr, h->d.net_pi, h->d.net_v, h->d.leaf_list + GT, h->opponent->stream);
+                if (rc) { h->err = h->opponent->err; return rc; }
+                HIPCHK(h, hipEventRecord(h->arena_ev, h->opponent->stream));
+            }
+            int rc = net_forward_counted(h, h->d.leaf_in, LEAF_STRIDE, NB_MAX, cnt_dev, beside ? cnt_dev + 1 : nullptr, h->d.net_pi, h->d.net_v, h->d.leaf_list, h->stream);
+            if (rc) return rc;
+            if (h->d.nodes2) HIPCHK(h, hipStreamWaitEvent(h->stream, h->arena_ev, 0));
+            if (p % CHUNK == CHUNK - 1 && p + 1 < passes) {
+                HIPCHK(h, hipMemcpy2DAsync(st0.data(), 4, &h->d.ctl[0].arena_state, sizeof(Ctl), 4, h->d.G, hipMemcpyDeviceToHost, h->stream));
+                SYNC(h);
+                bool all_idle = true;
+                for (uint32_t v : st0) all_idle = all_idle && v == 2;
+                if (all_idle) break;
+            }
+        }
+    } else
     if (h->d.nodes2) {  // two networks: every pass evaluates each net on the leaves of its own player only
-        const int GT = h->d.G * h->d.T;
         if (!h->arena_ev) HIPCHK(h, hipEventCreateWithFlags(&h->arena_ev, hipEventDisableTiming));
         for (int p = 0; p < passes; p++) {
             HIPCHK(h, hipMemsetAsync(h->d.leaf_count, 0, 2 * sizeof(int), h->stream));

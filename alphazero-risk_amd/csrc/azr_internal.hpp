@@ -85,7 +85,9 @@ struct Dev {
     uint16_t* freel2;
     uint32_t* tctl2;           // [G][4]  tree 2's {search_id, nfree, hiwater, -}
     int* leaf_list;            // [2][G*T] leaf slots waiting for net A / net B after an arena step
-    int* leaf_count;           // [2]
+    int* leaf_count;           // [2][2]: [0][net] by default; the arena's passes without a read-back alternate between the two rows
+    int lc_base;               // ... row (x 2) the arena step counts into
+    int lc_zero;               // ... row (x 2) the arena step zeroes for the next pass (nobody reads it any more), or -1
     int arena_collect;         // stage (s, pi, player) per AlphaZero decision and flush finished games to the record ring
 };
 constexpr int ALOG = 16;
@@ -132,6 +134,8 @@ struct azr_engine {
     bool weights_set;
     void* tree2[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // nodes2, touch2, nhash2, table2, freel2, tctl2
     azr_engine* opponent = nullptr;  // handle whose network plays AZR_PLAYER_ALPHAZERO_B (azr_arena_set_opponent_net)
+    unsigned arena_pass = 0;         // passes of the running arena that were queued without a read-back (parity = leaf_count row)
+    hipEvent_t arena_ev2 = nullptr;  // ... and this stream's tree step done -> the opponent's net launch may start
     hipEvent_t arena_ev = nullptr;   // two-net arena: the opponent's net launch (on ITS stream) done -> this stream may go on
     bool sp_tail = false;         // quota self-play: no game is left to start, slots go idle -> compacted net batches
     void* train = nullptr;        // azr_train.hip: optimiser state + activation slabs, created by the first azr_nn_train*
@@ -146,6 +150,8 @@ void net_free(azr_engine* h);
 int net_upload(azr_engine* h);  // fold BN, pack, copy h->flat to the device
 int net_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v);
 int net_forward_ex(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st);
+bool net_forward_counted_ok(azr_engine* h, int n_max);
+int net_forward_counted(azr_engine* h, const uint8_t* d_in88, int in_stride, int n_max, const int* n_dev, const int* n_other, float* d_pi, float* d_v, const int* d_map, hipStream_t st);
 size_t net_param_count(int blocks);
 void net_init_random(float* flat, int blocks, uint64_t seed);
 int net_fallbacks(azr_engine* h, unsigned long long* out);   // split-channel tower launches recomputed after a hand-off gave up

@@ -33,6 +33,8 @@ int net_bf16_alloc(azr_engine* h);
 void net_bf16_free(azr_engine* h);
 int net_bf16_upload(azr_engine* h, const float* fold_host);
 int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st);
+bool net_bf16_counted_ok(azr_engine* h, int n_max);
+int net_bf16_forward_counted(azr_engine* h, const uint8_t* d_in88, int in_stride, int n_max, const int* n_dev, const int* n_other, float* d_pi, float* d_v, const int* d_map, hipStream_t st);
 }  // namespace azr
 
 constexpr float BN_EPS = 1e-3f;  // tf.layers.batch_normalization default epsilon
@@ -401,6 +403,18 @@ int azr::net_forward_ex(azr_engine* h, const uint8_t* d_in88, int in_stride, int
     }
     if (h->cfg.net_dtype == AZR_NET_F32X) return net_fx_forward(h, d_in88, in_stride, n, d_pi, d_v, d_map, st);
     return net_bf16_forward(h, d_in88, in_stride, n, d_pi, d_v, d_map, st);
+}
+
+// forward of a batch whose size is the device word *n_dev (at most n_max boards), without a read-back: the 16-bit split-channel tower only
+bool azr::net_forward_counted_ok(azr_engine* h, int n_max)
+{
+    return (h->cfg.net_dtype == AZR_NET_BF16 || h->cfg.net_dtype == AZR_NET_F16) && h->net.bf16ctx && net_bf16_counted_ok(h, n_max);
+}
+
+int azr::net_forward_counted(azr_engine* h, const uint8_t* d_in88, int in_stride, int n_max, const int* n_dev, const int* n_other, float* d_pi, float* d_v, const int* d_map, hipStream_t st)
+{
+    if (!net_forward_counted_ok(h, n_max)) { h->err = "net_forward_counted: not available for this net / batch"; return AZR_E_STATE; }
+    return net_bf16_forward_counted(h, d_in88, in_stride, n_max, n_dev, n_other, d_pi, d_v, d_map, st);
 }
 
 namespace azr { int tower_sc_fallbacks(azr_engine* h, unsigned long long* out); }   // azr_tower_sc.hip

@@ -537,15 +537,27 @@ __global__ __launch_bounds__(1024 / NT, NT == 2 ? 2 : 1) void k_tower_bf16(const
                                                                            const float* __restrict__ hp,
                                                                            float* __restrict__ pi_out, float* __restrict__ v_out,
                                                                            unsigned long long* __restrict__ diag, int n_full,
-                                                                           const int* __restrict__ slot_map, unsigned* __restrict__ guard)
+                                                                           const int* __restrict__ slot_map, unsigned* __restrict__ guard,
+                                                                           const int* __restrict__ n_dev, unsigned tag)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int bid = blockIdx.x;
     // guard != null: this launch stands behind a k_tower_sc launch of the same batch and runs only if that one raised its give-up word
-    // (a hand-off ran out of polls: its results are garbage) — every workgroup ends here otherwise; workgroup 0 counts the recompute
+    // (1: a hand-off ran out of polls, its results are garbage; 2: more boards than it takes) — every workgroup ends here otherwise;
+    // workgroup 0 counts the recompute of a launch that gave up
+    // (the word holds (serial of the launch << 2) | reason; tag = this launch pair's serial << 2).  Workgroup 0 also zeroes the pairs' arrival
+    // counters and XCC words for the next k_tower_sc launch — this kernel is what runs between two of them in stream order.
     if (guard) {
-        if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(guard + SC_W_GIVEUP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) return;
-        if (bid == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(guard + SC_W_FALLBACKS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bid == 0 && threadIdx.x < SC_W_GIVEUP) guard[threadIdx.x] = 0u;
+        const unsigned word = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(guard + SC_W_GIVEUP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const int why = (word ^ tag) < 4u ? (int)(word & 3u) : 0;
+        if (why == 0) return;
+        if (why == 1 && bid == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(guard + SC_W_FALLBACKS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // n_dev != null (NB = 1 only): the batch size is a word in device memory, the grid covers the largest batch
+    if (n_dev) {
+        n = n_full = __builtin_amdgcn_readfirstlane(*n_dev);
+        if (bid >= n) return;
     }
     if constexpr (NB >= 2) {
         if (bid >= n_full) {
@@ -730,11 +742,42 @@ int net_bf16_forward(azr_engine* h, const uint8_t* d_in88, int in_stride, int n,
     // AZR_TOWER_SB=0 / AZR_TOWER_SC=0: one board per workgroup for the whole net, two ping-pong images, 8 waves x 32 channels
     if (x->f16)
         hipLaunchKernelGGL((k_tower_bf16<1, 2, true>), dim3(n), dim3(512), Geo<1>::LDS_BYTES, st, d_in88, in_stride, n, x->stem_wp, x->tower_wp,
-                           (const float*)x->fold16, B, net_head_params(h), d_pi, d_v, x->diag, n, d_map, guard);
+                           (const float*)x->fold16, B, net_head_params(h), d_pi, d_v, x->diag, n, d_map, guard, nullptr, x->sc_tag);
     else
         hipLaunchKernelGGL((k_tower_bf16<1, 2, false>), dim3(n), dim3(512), Geo<1>::LDS_BYTES, st, d_in88, in_stride, n, x->stem_wp, x->tower_wp, fold, B,
-                           net_head_params(h), d_pi, d_v, x->diag, n, d_map, guard);
+                           net_head_params(h), d_pi, d_v, x->diag, n, d_map, guard, nullptr, x->sc_tag);
     if (h->pe_tower1 && !guard) hipEventRecord(h->pe_tower1, st);
+    HIPCHK(h, hipGetLastError());
+    return AZR_OK;
+}
+
+// Small batches whose size only the device knows (the arena's and the emptying self-play tail's waiting leaves, counted by the tree step
+// into *n_dev ahead of this call in stream order): no read-back, no host synchronisation per pass.  Both launches are sized for n_max
+// (<= 256) boards and read the count themselves: the split-channel tower takes up to 128 boards, above that — or when the launch of another
+// network beside it (n_other: that one's count) leaves it no CU per workgroup — it raises the give-up word with the value 2 and the guarded
+// one-board-per-workgroup launch computes the batch; a count of 0 ends every workgroup at once.
+bool net_bf16_counted_ok(azr_engine* h, int n_max)
+{
+    Bf16Net* x = bn(h);
+    return x && x->sb_mode == 1 && x->sc_mode != 0 && n_max >= 1 && n_max <= 256;   // the product's plan (no forced tile of the test build)
+}
+
+int net_bf16_forward_counted(azr_engine* h, const uint8_t* d_in88, int in_stride, int n_max, const int* n_dev, const int* n_other, float* d_pi, float* d_v,
+                             const int* d_map, hipStream_t st)
+{
+    if (!net_bf16_counted_ok(h, n_max) || !n_dev) { h->err = "net_bf16_forward_counted: 1..256 boards on the split-channel tower"; return AZR_E_INVALID_ARGUMENT; }
+    Bf16Net* x = bn(h);
+    const int B = h->net.blocks;
+    if (h->pe_tower0) hipEventRecord(h->pe_tower0, st);
+    int rc = tower_sc_launch(h, d_in88, in_stride, n_max, d_pi, d_v, d_map, st, n_dev, n_other);
+    if (h->pe_tower1) hipEventRecord(h->pe_tower1, st);
+    if (rc) return rc;
+    if (x->f16)
+        hipLaunchKernelGGL((k_tower_bf16<1, 2, true>), dim3(n_max), dim3(512), Geo<1>::LDS_BYTES, st, d_in88, in_stride, n_max, x->stem_wp, x->tower_wp,
+                           (const float*)x->fold16, B, net_head_params(h), d_pi, d_v, (unsigned long long*)nullptr, n_max, d_map, x->sc_counters, n_dev, x->sc_tag);
+    else
+        hipLaunchKernelGGL((k_tower_bf16<1, 2, false>), dim3(n_max), dim3(512), Geo<1>::LDS_BYTES, st, d_in88, in_stride, n_max, x->stem_wp, x->tower_wp,
+                           net_fold(h), B, net_head_params(h), d_pi, d_v, (unsigned long long*)nullptr, n_max, d_map, x->sc_counters, n_dev, x->sc_tag);
     HIPCHK(h, hipGetLastError());
     return AZR_OK;
 }

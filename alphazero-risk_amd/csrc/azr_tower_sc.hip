@@ -63,6 +63,7 @@ typedef __attribute__((ext_vector_type(2))) short s16x2;
 namespace {
 constexpr int NB = 2, ROWS = 84, MT = 6, ZR = 96, THREADS = 256;
 constexpr int MAX_PAIRS = 64;                        // board pairs of one launch (128 boards)
+constexpr int CUS = 256;                              // compute units of the part (MI355X)
 constexpr int CGN = 4;                                // workgroups per board pair: 64 output channels each
 constexpr int MTW = 3, NTW = 2;                       // a wave's tile: 3 row tiles (one half of the pair's 96 rows) x 2 column tiles (32 channels)
 constexpr int RING = 12;                              // weight ring depth in k-steps (72 = 0 mod RING): 22 KB in flight per wave
@@ -70,7 +71,7 @@ constexpr int IMG = (ZR + 1) * ROWB;                  // the pair's activation i
 constexpr uint32_t EX_PAIR_BYTES = ZR * NF * 2;       // one pair's exchange image: [96 rows][256] bf16, no pad
 constexpr int AUX_SC1 = 16;                           // cache-policy bits of the raw buffer builtins: sc1 (write-through store / L1-bypassing load)
 constexpr unsigned SPIN_LIMIT = 1u << 21;             // polls of a hand-off before the launch gives up (~1 s)
-constexpr int W_GIVEUP = 2 * MAX_PAIRS;               // word of the counter block: raised by a hand-off that ran out of polls (zeroed per launch)
+constexpr int W_GIVEUP = 2 * MAX_PAIRS;               // word of the counter block: raised by a hand-off that ran out of polls: (serial of the launch << 2) | 1; | 2 = more boards than 128
 constexpr int W_FALLBACKS = 2 * MAX_PAIRS + 1;        // ... launches the guarded one-board-per-workgroup kernel had to recompute (never zeroed)
 
 // LDS map (dynamic): image | stem features | NNInputData images | tables | heads scratch
@@ -194,7 +195,7 @@ __device__ __forceinline__ void count_in(int tid, unsigned* counter)
 // stored by nobody and fetched by nobody.  A poll that runs out of spins raises the launch's give-up word (device memory, agent scope)
 // and goes on with whatever the image holds; once the word is up nobody waits any more (the launch is lost: it only has to end).
 __device__ __forceinline__ void gather(uint8_t* bufX, int epoch, int pair, int cg, int tid, const __amdgpu_buffer_rsrc_t ex, unsigned* counter, unsigned* giveup,
-                                       unsigned spin_limit)
+                                       unsigned tag, unsigned spin_limit)
 {
     constexpr int UNITS = ZR * 32 / THREADS;   // 16-byte units per thread over the whole [96][512 B] image: rows (tid >> 5) + 8 i, segment tid & 31
     const uint32_t img_off = (uint32_t)(pair * 2 + (epoch & 1)) * EX_PAIR_BYTES;
@@ -202,8 +203,8 @@ __device__ __forceinline__ void gather(uint8_t* bufX, int epoch, int pair, int c
         const unsigned want = (unsigned)(CGN * epoch);
         unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-            if (spins >= spin_limit) { __hip_atomic_store(giveup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            if ((spins & 255u) == 255u && __hip_atomic_load(giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            if (spins >= spin_limit) { __hip_atomic_store(giveup, tag | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if ((spins & 255u) == 255u && (__hip_atomic_load(giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ^ tag) < 4u) break;
             spins++;
             __builtin_amdgcn_s_sleep(1);
         }
@@ -313,7 +314,7 @@ __device__ __forceinline__ void layer_half(const uint8_t* bufX, const uint8_t* t
 template <bool F16>
 __device__ __forceinline__ bool sc_run(uint8_t* lds, int pair, int cg, int blocks, const uint16_t* __restrict__ stem_wp, const uint16_t* __restrict__ tower_wp,
                                        uint32_t tower_bytes, const float* __restrict__ fold, uint8_t* __restrict__ ex_base, uint32_t ex_bytes_total,
-                                       unsigned* counter, unsigned* giveup, unsigned spin_limit, int force_wt)
+                                       unsigned* counter, unsigned* giveup, unsigned tag, unsigned spin_limit, int force_wt)
 {
     // which XCD this workgroup runs on: every workgroup of the pair adds 1 to the 3-bit field of its XCC in the pair's word before its
     // stem stores are drained and counted; behind the stem's hand-off the word says whether all four share one XCD (speed only: the
@@ -347,7 +348,7 @@ __device__ __forceinline__ bool sc_run(uint8_t* lds, int pair, int cg, int block
     if (mh) publish_stores<1>(o, 1, pair, ct0, c, g, ex, false); else publish_stores<0>(o, 1, pair, ct0, c, g, ex, false);
     count_in(tid, counter);
     if (mh) own_to_lds<1>(bufX, o, ct0, c, g); else own_to_lds<0>(bufX, o, ct0, c, g);
-    gather(bufX, 1, pair, cg, tid, ex, counter, giveup, spin_limit);
+    gather(bufX, 1, pair, cg, tid, ex, counter, giveup, tag, spin_limit);
     // (thread 0's add above was drained with the stem's stores — vmcnt(0) in count_in — before this workgroup was counted in)
     const bool same_xcd = !force_wt &&
         __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(xccw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == (int)((unsigned)CGN << (3u * xcc));
@@ -380,7 +381,7 @@ __device__ __forceinline__ bool sc_run(uint8_t* lds, int pair, int cg, int block
                 for (int nt = 0; nt < NTW; nt++)
                     bq[ks][nt] = __builtin_amdgcn_raw_buffer_load_b128(wsrc, loff + nt * 1024, (int)(wk + (uint32_t)ks * (uint32_t)KBYTES), 0);
         }
-        gather(bufX, L + 2, pair, cg, tid, ex, counter, giveup, spin_limit);
+        gather(bufX, L + 2, pair, cg, tid, ex, counter, giveup, tag, spin_limit);
     }
     return true;
 }
@@ -391,8 +392,31 @@ __global__ __launch_bounds__(THREADS) void k_tower_sc(const uint8_t* __restrict_
                                                        const float* __restrict__ fold, int blocks, const float* __restrict__ hp,
                                                        float* __restrict__ pi_out, float* __restrict__ v_out, const int* __restrict__ slot_map,
                                                        uint8_t* __restrict__ ex_base, uint32_t ex_bytes_total, unsigned* __restrict__ counters,
-                                                       unsigned spin_limit, int force_wt)
+                                                       unsigned spin_limit, int force_wt, const int* __restrict__ n_dev, unsigned tag, const int* __restrict__ n_other)
 {
+    // n_dev != null: the batch size is a word in device memory (written by the tree step ahead of this launch in stream order; the grid
+    // was sized for the largest batch).  More boards than this kernel takes: the give-up word is raised with the value 2 — the guarded
+    // one-board-per-workgroup launch behind this one computes the batch, and does not count it as a hand-off that gave up.
+    // n_other != null: the batch of ANOTHER network's launch that runs side by side with this one (the two-net arena).  Four workgroups per
+    // board pair pay only while every workgroup has a CU to itself (two per CU: 0.70 ms against 0.43, profiles/r03_small_batch_tower.txt —
+    // measured again in the arena's trace, profiles/r04_arena_passes.txt: 0.66 ms for the second of two 100-board launches).  So both
+    // launches take this kernel only if their workgroups fit the 256 CUs together; else both go one board per workgroup (letting the
+    // smaller batch keep this kernel beside the larger one's one-board workgroups measured slower: it slows the larger, which the pass
+    // waits for).  Both launches evaluate the same rule on the same two words.
+    if (n_dev) {
+        n = __builtin_amdgcn_readfirstlane(*n_dev);
+        pairs = (n + 1) / 2;
+        bool here = n <= 2 * MAX_PAIRS;
+        if (here && n_other) {
+            const int m = __builtin_amdgcn_readfirstlane(*n_other);
+            const int wg_n = CGN * ((n + 1) / 2), wg_m = CGN * ((m + 1) / 2);
+            if (m > 0 && wg_n + wg_m > CUS) here = false;
+        }
+        if (!here) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(counters + W_GIVEUP, tag | 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
     // block id -> (pair, channel group): the CGN workgroups of a pair are 8 ids apart
     const int grp = blockIdx.x / (8 * CGN), r = blockIdx.x % (8 * CGN), cg = r / 8, pair = grp * 8 + (r & 7);
     if (pair >= pairs) return;   // (padding of the last group of 8 pairs: belongs to no pair, waits for nobody)
@@ -444,7 +468,7 @@ __global__ __launch_bounds__(THREADS) void k_tower_sc(const uint8_t* __restrict_
     __syncthreads();
 
     // ---- stem and tower
-    if (!sc_run<F16>(lds, pair, cg, blocks, stem_wp, tower_wp, tower_bytes, fold, ex_base, ex_bytes_total, counters + pair, counters + W_GIVEUP, spin_limit, force_wt))
+    if (!sc_run<F16>(lds, pair, cg, blocks, stem_wp, tower_wp, tower_bytes, fold, ex_base, ex_bytes_total, counters + pair, counters + W_GIVEUP, tag, spin_limit, force_wt))
         return;
 
     // ---- both heads for the pair (k_tower_sb's fused heads), channel group 0 only
@@ -558,22 +582,29 @@ void tower_sc_free(azr_engine* h)
 
 // the whole net for n <= 128 boards in one persistent launch of 4 workgroups per board pair.  The caller queues the guarded
 // one-board-per-workgroup launch right behind it (net_bf16_forward): if a hand-off of this launch gave up, that one recomputes the batch.
-int tower_sc_launch(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st)
+// n_dev != null: the batch size is read from that word of device memory by the launch itself and n is only its upper bound (the grid);
+// n_other (optional): the batch-size word of another network's launch running beside this one (see the kernel).
+int tower_sc_launch(azr_engine* h, const uint8_t* d_in88, int in_stride, int n, float* d_pi, float* d_v, const int* d_map, hipStream_t st,
+                    const int* n_dev, const int* n_other)
 {
+    if (n_dev && n > 2 * MAX_PAIRS) n = 2 * MAX_PAIRS;
     if (n < 1 || n > 2 * MAX_PAIRS) { h->err = "tower_sc_launch: 1..128 boards"; return AZR_E_INVALID_ARGUMENT; }
     Bf16Net* x = bf16net(h);
     const int pairs = (n + 1) / 2, B = h->net.blocks;
     const int wgs = ((pairs + 7) / 8) * 8 * CGN;     // whole groups of 8 pairs (ids of a pair's workgroups are 8 apart)
     const uint32_t tower_bytes = (uint32_t)(((size_t)2 * B * TOWER_LAYER_HALFS + MAX_RING * KSTRIDE * 8) * 2);
     const uint32_t ex_bytes = (uint32_t)((size_t)2 * MAX_PAIRS * EX_PAIR_BYTES);
-    // the arrival counters and the give-up word count within ONE launch: zeroed ahead of it, in stream order
-    HIPCHK(h, hipMemsetAsync(x->sc_counters, 0, (W_GIVEUP + 1) * sizeof(unsigned), st));
+    // The pairs' words count within ONE launch: the guarded launch the caller queues behind this one zeroes them again (workgroup 0, before
+    // anything else) — no memset in front of a launch.  The give-up word carries the launch's serial number in its upper 30 bits: what an
+    // earlier launch left there is nobody's business.
+    x->sc_tag = (++x->sc_serial & 0x3fffffffu) << 2;
+    const unsigned tag = x->sc_tag;
     if (x->f16)
         hipLaunchKernelGGL(k_tower_sc<true>, dim3(wgs), dim3(THREADS), LDS_BYTES, st, d_in88, in_stride, n, pairs, x->stem_wp, x->tower_wp, tower_bytes, (const float*)x->fold16, B,
-                           net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_spin_limit, x->sc_force_wt);
+                           net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_spin_limit, x->sc_force_wt, n_dev, tag, n_other);
     else
         hipLaunchKernelGGL(k_tower_sc<false>, dim3(wgs), dim3(THREADS), LDS_BYTES, st, d_in88, in_stride, n, pairs, x->stem_wp, x->tower_wp, tower_bytes, net_fold(h), B,
-                           net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_spin_limit, x->sc_force_wt);
+                           net_head_params(h), d_pi, d_v, d_map, reinterpret_cast<uint8_t*>(x->sc_ex), ex_bytes, x->sc_counters, x->sc_spin_limit, x->sc_force_wt, n_dev, tag, n_other);
     HIPCHK(h, hipGetLastError());
     return AZR_OK;
 }

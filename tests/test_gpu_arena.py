@@ -236,3 +236,41 @@ def test_concurrent_pair_halves_two_net_arena_bit_exact_with_samples(orc, thread
     assert [res["count"], res["draw"], res["win"][0], res["win_and_started"][0], res["win"][1], res["win_and_started"][1]] == list(tot)
     a.arena_set_opponent(None)
     a.close(); b.close()
+
+
+# ---- passes queued without a read-back (azr_arena_run, up to 256 leaf slots on the 16-bit towers) ---------------------------------
+@pytest.mark.parametrize("two_nets", [False, True])
+def test_passes_without_a_read_back_equal_the_read_back_form(monkeypatch, two_nets):
+    """The net launches of an arena of <= 256 leaf slots read the tree step's leaf count from device memory (net_forward_counted): the
+    same arena through the read-back form (AZR_ARENA_COUNTED=0, test build) must give the same games and records.  128 slots x T = 2
+    with the AlphaZero player first: the opening passes carry 256 leaves for one net — more than the split-channel tower takes; the
+    launch says so in its give-up word (value 2) and the one-board-per-workgroup launch behind it computes them, not counted as a
+    hand-off that gave up."""
+    P = pkg()
+    G, S, B, base = 128, 6, 1, 9100
+    out = []
+    for counted in (True, False):
+        if not counted:
+            monkeypatch.setenv("AZR_ARENA_COUNTED", "0")
+        a = P.Engine(G, blocks=B, sims=S, dtype=P.NET_BF16, threads=2, max_game_rounds=30, test_hooks=not counted)
+        a.set_weights(T.make_net_flat(B, seed=41, perturb_bn=True))
+        b = None
+        if two_nets:
+            b = P.Engine(G, blocks=B, sims=S, dtype=P.NET_BF16, threads=2, max_game_rounds=30, test_hooks=not counted)
+            b.set_weights(T.make_net_flat(B, seed=42, perturb_bn=True))
+            a.arena_set_opponent(b)
+        a.arena_collect_samples(True)
+        k = (P.PLAYER_ALPHAZERO, P.PLAYER_ALPHAZERO_B) if two_nets else (P.PLAYER_ALPHAZERO, P.PLAYER_SCRIPT)
+        res, (n, st, rd, fin) = run_arena(a, k[0], k[1], 256, 0, P.MIRROR_SEQUENTIAL, base)
+        c = a.counters()
+        assert c["errors"] == 0 and c["nodes_dropped"] == 0 and c["tower_fallbacks"] == 0 and c["records_dropped"] == 0
+        recs = a.drain()
+        out.append((res, n.copy(), st.copy(), rd.copy(), fin.copy(), b"".join(sorted(r.tobytes() for r in recs))))
+        if two_nets:
+            a.arena_set_opponent(None)
+            b.close()
+        a.close()
+    assert out[0][0] == out[1][0] and out[0][0]["count"] == 256
+    for x, y in zip(out[0][1:5], out[1][1:5]):
+        assert (x == y).all()
+    assert len(out[0][5]) > 0 and out[0][5] == out[1][5]
