@@ -15,7 +15,7 @@
 // products, so ReLU masks and batch statistics are those of an fp32 forward), the two gradient GEMMs use two parts (3
 // passes, 1e-5 relative) — with t_gemm on the fp32 MFMA (v_mfma_f32_32x32x2_f32) kept for the stem (K = 144), odd
 // batch sizes and AZR_TRAIN_GEMM=f32.  Kernels of the split path: t_conv_rs / t_conv_q (forward on fp16 pairs, backward-data on two
-// bf16 parts, with the normalise and statistics steps fused into their staging paths and epilogues) and t_wgrad_rs (weight gradient).
+// bf16 parts, with the normalise and statistics steps fused into their staging paths and epilogues) and t_wgrad_g5 (weight gradient).
 // Every conv output (pre-BN) and every post-activation is kept for the backward pass: 2 x 22 MB per layer at batch 512,
 // 1.8 GB for the 41 conv layers of B = 20 — sized for 288 GB of HBM, nothing is recomputed.
 // Reductions (BN statistics, bias / BN / head gradients, split-K) are two-stage and atomic-free: a step is
@@ -1049,6 +1049,20 @@ __global__ __launch_bounds__(256, 1) void t_conv_q(Parts A, Parts Bp, float* __r
     }
 }
 
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// transposed read of one MFMA operand fragment: two 4-row blocks (rows k..k+3 of the lane's group, then k+4..k+7); the
+// arguments are absolute LDS addresses (no base to add), IMM a compile-time byte offset that lands in the instruction
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+template <int IMM>
+__device__ __forceinline__ s16x8 lds_tr8(uint32_t a_lo, uint32_t a_hi)
+{
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>((uintptr_t)a_lo) + IMM / 8);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>((uintptr_t)a_hi) + IMM / 8);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+#ifdef AZR_TEST_HOOKS   // the older formulation of the weight gradient: libazr_hip_test.so only (AZR_TRAIN_WGRAD=rs), what t_wgrad_g5 is compared with
 // ---------------------------------------------------------------------------------------------------------------------
 // t_wgrad_rs: the weight gradient  dW[tap][ci][co] = sum over rows of A[row + tap][ci] * dY[row][co]  (split bf16, 3 passes).
 // The reduction runs over ROWS, the slow index of both operands ([row][channel] in memory): the MFMA wants 8 consecutive
@@ -1075,19 +1089,6 @@ struct Wg {
     static constexpr int BUF = 2 * APB + 2 * GPB;  // A part 0 | A part 1 | dY part 0 | dY part 1
     static constexpr int LDS_BYTES = BUF;          // ONE buffer: a wave's LDS operations run in program order (see t_wgrad_rs)
 };
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-
-// transposed read of one MFMA operand fragment: two 4-row blocks (rows k..k+3 of the lane's group, then k+4..k+7); the
-// arguments are absolute LDS addresses (no base to add), IMM a compile-time byte offset that lands in the instruction
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-template <int IMM>
-__device__ __forceinline__ s16x8 lds_tr8(uint32_t a_lo, uint32_t a_hi)
-{
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>((uintptr_t)a_lo) + IMM / 8);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>((uintptr_t)a_hi) + IMM / 8);
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
 // one k-step (32 rows) of t_wgrad_rs.  With one wave per SIMD nothing hides a latency: the A fragments of tap t + 1 are
 // requested BEFORE the 12 MFMAs of tap t are issued (two fragment slots, pinned with scheduling barriers — left alone, the
 // compiler reuses one slot and waits for every read in front of its MFMAs), and everything else is kept to the reads
@@ -1246,6 +1247,255 @@ __global__ __launch_bounds__(64, 1) void t_wgrad_rs(Parts A, Parts G, float* __r
         wg_kstep(pos1, pos2, aoff, a_zero, g_lo, g_hi, acc);
         asm volatile("" ::: "memory");   //  ... and the stores of the next tile follow the reads)
         if (ks + 1 < nks) stash();
+    }
+    float* o = out + (size_t)slice * KC * NF;
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                o[(size_t)(t * NF + cit * 16 + 4 * g + e) * NF + wq * 64 + c * 16 + i16] = acc[t][c][e];
+}
+#endif   // AZR_TEST_HOOKS
+
+// ---------------------------------------------------------------------------------------------------------------------
+// t_wgrad_g5: the same weight gradient with the reduction index laid out so that the 3 x 3 taps share operand fragments.
+// t_wgrad_rs reduces over rows in memory order: every tap is its own shift of the A rows, so a k-step reads 9 x 2 A fragments from LDS
+// for 108 MFMAs, and its 52 transposed reads per wave (4 waves per CU) hold the matrix pipe at one half.  Here a k-step is ONE BOARD ROW
+// y OF FIVE BOARDS: k = 6 j + x (board j of the group, column x; k = 30, 31 are zero).  Then
+//   * the dy shift of a tap is a shift by whole k-steps: the A fragments of board row y + dy are those read for k-step y + dy — a
+//     fragment is read from LDS ONCE and serves three k-steps out of a ring of three rows in registers (3 dx x 2 parts x 3 rows);
+//   * the dx shift is the lane's source-row address, loop-invariant (x = k mod 6 belongs to the lane): no edge tests in the loop;
+//   * taps that leave the board vertically are whole k-steps of zeros and are skipped (y = 0: dy = -1, y = 6: dy = +1): 57 of 63
+//     tap-rows per group, which pays for the 2 idle k of 32;
+//   * per k-step 12 A reads + 16 dY reads instead of 36 + 16, 10 KB of tile stores instead of 12, no halo rows.
+// The k-steps of a slice form one flat sequence s (7 per group of 5 boards; "row 7" of a group is row 0 of the next, and the taps that
+// would mix them are the skipped ones).  In k-step s the LDS tile holds {dY(s + 1), A(s + 2)}: stored at the start of the k-step (its
+// global loads were issued one k-step earlier), read into the NEXT fragment registers while this k-step's MFMAs run from registers —
+// the dY fragments at once, the A fragments into the ring slot of row s - 1 once that row's taps (dy = -1) are done.  Ring slots and
+// the dY double buffer are compile-time: the loop body is six k-steps.
+// Measured (batch 512, one box, rocprofv3 averages over 1000 launches; profiles/r04_train_step.txt): 62.2 us against 68.9 for t_wgrad_rs
+// (64.3 before the memory operations were dealt between the MFMAs).  Of the 62: 39 are the 4788 MFMAs of a block (7 groups x 7 k-steps),
+// ~9 the 35 MB of split-K partials that all 960 waves write at the same moment, ~3 the prologue's three dependent round trips.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+struct Wg5 {
+    static constexpr int GB = 5, KR = 32, ROWS_Y = 7;
+    static constexpr int AST = 32;                                     // bytes per row of the A tile (16 ci)
+    __host__ __device__ static constexpr int arow(int r) { return r * AST + (r >> 3) * 128; }   // rows 0 .. 31, row 32 = the zero row
+    static constexpr int APB = 33 * AST + 5 * 128;
+    static constexpr int GST = 160;
+    __host__ __device__ static constexpr int grow(int r) { return r * GST + (r >> 3) * 128; }
+    static constexpr int GPB = KR * GST + (KR / 8) * 128;
+    static constexpr int LDS_BYTES = 2 * APB + 2 * GPB;               // A part 0 | A part 1 | dY part 0 | dY part 1
+};
+
+template <int T>
+__device__ __forceinline__ void g5_tap(const s16x8 (&a)[2], const s16x8 (&gf)[2][4], f32x4 (&acc)[9][4])
+{
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        acc[T][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, gf[0][c]), acc[T][c], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        acc[T][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, gf[1][c]), acc[T][c], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        acc[T][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, gf[0][c]), acc[T][c], 0, 0, 0);
+}
+// the three taps of one dy: row fragments r[dx][part] against the k-step's dY fragments
+template <int DY>
+__device__ __forceinline__ void g5_taps(const s16x8 (&r)[3][2], const s16x8 (&gf)[2][4], f32x4 (&acc)[9][4])
+{
+    g5_tap<(DY + 1) * 3 + 0>(r[0], gf, acc);
+    g5_tap<(DY + 1) * 3 + 1>(r[1], gf, acc);
+    g5_tap<(DY + 1) * 3 + 2>(r[2], gf, acc);
+}
+__device__ __forceinline__ void g5_read_g(uint32_t g_lo, uint32_t g_hi, s16x8 (&gf)[2][4])
+{
+    gf[0][0] = lds_tr8<0>(g_lo, g_hi); gf[0][1] = lds_tr8<32>(g_lo, g_hi); gf[0][2] = lds_tr8<64>(g_lo, g_hi); gf[0][3] = lds_tr8<96>(g_lo, g_hi);
+    gf[1][0] = lds_tr8<Wg5::GPB>(g_lo, g_hi); gf[1][1] = lds_tr8<Wg5::GPB + 32>(g_lo, g_hi);
+    gf[1][2] = lds_tr8<Wg5::GPB + 64>(g_lo, g_hi); gf[1][3] = lds_tr8<Wg5::GPB + 96>(g_lo, g_hi);
+}
+__device__ __forceinline__ void g5_read_a(const uint32_t (&aoff)[3][2], s16x8 (&r)[3][2])
+{
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        r[d][0] = lds_tr8<0>(aoff[d][0], aoff[d][1]);
+        r[d][1] = lds_tr8<Wg5::APB>(aoff[d][0], aoff[d][1]);
+    }
+}
+
+__global__ __launch_bounds__(64, 1) void t_wgrad_g5(Parts A, Parts G, float* __restrict__ out, int boards, int NS, int boards_per_slice)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t wg_lds[];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    const int slice = blockIdx.x % NS, rest = blockIdx.x / NS, cit = rest & 15, wq = rest >> 4;   // wq = which 64 co columns
+    const int bbeg = slice * boards_per_slice, bend = min(boards, bbeg + boards_per_slice);
+    const int S = Wg5::ROWS_Y * ((bend - bbeg + Wg5::GB - 1) / Wg5::GB);   // k-steps of the slice
+
+    if (lane < 2 * (Wg5::AST / 4))   // zero rows of the two A parts
+        reinterpret_cast<uint32_t*>(wg_lds + (lane / (Wg5::AST / 4)) * Wg5::APB + Wg5::arow(32))[lane % (Wg5::AST / 4)] = 0u;
+
+    // Staging units of this lane: 8 of the dY tile (4 (tile row, 16-byte segment) pairs x 2 parts) and 2 of the A tile (one per part).
+    // Tile row k = board 6 j + column x of the group; rows 30, 31 and the boards past the slice are out of range of the buffer resources
+    // (everything is in the vector offset, which the range check sees) and arrive as zeros.
+    const uint32_t range = (uint32_t)bend * NPOS * NF * 2u;
+    const __amdgpu_buffer_rsrc_t gsrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(G.p[0]), (short)0, range, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(G.p[1]), (short)0, range, 0x00020000);
+    const __amdgpu_buffer_rsrc_t asrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A.p[0]), (short)0, range, 0x00020000);
+    const __amdgpu_buffer_rsrc_t asrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A.p[1]), (short)0, range, 0x00020000);
+    constexpr uint32_t OOR = 0xfffffff0u;
+    uint32_t gvo[4], gl[4], avo, al;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int k = i * 8 + (lane >> 3), seg = lane & 7;
+        gvo[i] = k < 30 ? (uint32_t)((((bbeg + k / 6) * NPOS + k % 6) * NF + wq * 64 + seg * 8) * 2) : OOR;
+        gl[i] = (uint32_t)(2 * Wg5::APB + Wg5::grow(k) + seg * 16);
+    }
+    {
+        const int k = lane >> 1, seg = lane & 1;
+        avo = k < 30 ? (uint32_t)((((bbeg + k / 6) * NPOS + k % 6) * NF + cit * 16 + seg * 8) * 2) : OOR;
+        al = (uint32_t)(Wg5::arow(k) + seg * 16);
+    }
+    // byte offset of flat k-step s: group s / 7 (5 boards further each), board row s % 7
+    auto step_off = [](int s) -> uint32_t { return (uint32_t)(((s / Wg5::ROWS_Y) * Wg5::GB * NPOS + (s % Wg5::ROWS_Y) * 6) * NF * 2); };
+    u32x4 sg[8], sa[2];
+    auto fetch_g = [&](int s) {
+        const uint32_t so = step_off(s);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t vo = gvo[i] == OOR ? OOR : gvo[i] + so;
+            sg[i] = __builtin_amdgcn_raw_buffer_load_b128(gsrc0, vo, 0, 0);
+            sg[i + 4] = __builtin_amdgcn_raw_buffer_load_b128(gsrc1, vo, 0, 0);
+        }
+    };
+    auto fetch_a = [&](int s) {
+        const uint32_t vo = avo == OOR ? OOR : avo + step_off(s);
+        sa[0] = __builtin_amdgcn_raw_buffer_load_b128(asrc0, vo, 0, 0);
+        sa[1] = __builtin_amdgcn_raw_buffer_load_b128(asrc1, vo, 0, 0);
+    };
+    auto stash_g = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            *reinterpret_cast<u32x4*>(wg_lds + gl[i]) = sg[i];
+            *reinterpret_cast<u32x4*>(wg_lds + Wg5::GPB + gl[i]) = sg[i + 4];
+        }
+    };
+    auto stash_a = [&]() {
+        *reinterpret_cast<u32x4*>(wg_lds + al) = sa[0];
+        *reinterpret_cast<u32x4*>(wg_lds + Wg5::APB + al) = sa[1];
+    };
+
+    // the two tile rows this lane addresses in a transposed read (k1 = 8 g + q and k1 + 4), their columns, and per dx the LDS address of
+    // the source row: k + dx inside the board row, the zero row outside it (and for the idle k = 30, 31)
+    const int k1 = 8 * g + q, k2 = k1 + 4;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)wg_lds;
+    const uint32_t a_zero = lbase + (uint32_t)(Wg5::arow(32) + p * 8);
+    uint32_t aoff[3][2];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const int x1 = k1 % 6 + d - 1, x2 = k2 % 6 + d - 1;
+        aoff[d][0] = (k1 < 30 && x1 >= 0 && x1 < 6) ? lbase + (uint32_t)(Wg5::arow(k1 + d - 1) + p * 8) : a_zero;
+        aoff[d][1] = (k2 < 30 && x2 >= 0 && x2 < 6) ? lbase + (uint32_t)(Wg5::arow(k2 + d - 1) + p * 8) : a_zero;
+    }
+    const uint32_t g_lo = lbase + (uint32_t)(2 * Wg5::APB + Wg5::grow(k1) + p * 8);
+    const uint32_t g_hi = lbase + (uint32_t)(2 * Wg5::APB + Wg5::grow(k2) + p * 8);
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s16x8 R[3][3][2];    // A fragments [ring slot = board-row index mod 3][dx][part]
+    s16x8 gf[2][2][4];   // dY fragments [k-step mod 2][part][co tile]
+
+    // prologue: A(0) -> ring slot 0; tile 0 = {dY(0), A(1)} -> gf[0], ring slot 1; tile 1 on its way
+    fetch_a(0);
+    stash_a();
+    asm volatile("" ::: "memory");
+    g5_read_a(aoff, R[0]);
+    fetch_g(0); fetch_a(1);
+    asm volatile("" ::: "memory");
+    stash_g(); stash_a();
+    asm volatile("" ::: "memory");
+    g5_read_g(g_lo, g_hi, gf[0]);
+    g5_read_a(aoff, R[1]);
+    fetch_g(1); fetch_a(2);
+
+    // One k-step = one straight-line piece of code per (ring phase, board edge), cut into SLOTS of one tap (12 MFMAs) each.  The 48 memory
+    // instructions of the k-step — 10 tile stores, 10 global loads, 16 dY fragment reads, 12 A fragment reads — are dealt over the slots
+    // (6 per slot of a nine-tap k-step, 8 of a six-tap one) and inside a slot one is issued behind each of the first MFMAs
+    // (sched_group_barrier; a slot is one scheduling region): a lone wave issues in order, and ten stores or sixteen reads in a row in
+    // front of the MFMAs leave the matrix pipe idle for as long as they take to issue.
+    // Operation k of a k-step: 0 - 9 tile stores (W), 10 - 19 global loads (F), 20 - 27 dY fragments (two reads each), 28 - 33 A fragments.
+    int y = 0;
+    auto kstep = [&](auto ph, int s) {
+        constexpr int PH = decltype(ph)::value;
+        constexpr int rm = (PH + 2) % 3, r0 = PH % 3, rp = (PH + 1) % 3, gc = PH % 2, gn = (PH + 1) % 2;
+        const uint32_t so_g = step_off(s + 2), so_a = step_off(s + 3);   // tile s + 2 = {dY(s + 2), A(s + 3)} (zeros past the slice: nobody multiplies them)
+        uint32_t vg[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) vg[i] = gvo[i] == OOR ? OOR : gvo[i] + so_g;
+        const uint32_t va = avo == OOR ? OOR : avo + so_a;
+        auto op = [&](auto kk) {
+            constexpr int K = decltype(kk)::value;
+            if constexpr (K < 4) *reinterpret_cast<u32x4*>(wg_lds + gl[K]) = sg[K];                        // tile s + 1 = {dY(s + 1), A(s + 2)} over tile s:
+            else if constexpr (K < 8) *reinterpret_cast<u32x4*>(wg_lds + Wg5::GPB + gl[K - 4]) = sg[K];    // every read of tile s was issued in k-step s - 1
+            else if constexpr (K == 8) *reinterpret_cast<u32x4*>(wg_lds + al) = sa[0];
+            else if constexpr (K == 9) *reinterpret_cast<u32x4*>(wg_lds + Wg5::APB + al) = sa[1];
+            else if constexpr (K < 14) sg[K - 10] = __builtin_amdgcn_raw_buffer_load_b128(gsrc0, vg[K - 10], 0, 0);
+            else if constexpr (K < 18) sg[K - 10] = __builtin_amdgcn_raw_buffer_load_b128(gsrc1, vg[K - 14], 0, 0);
+            else if constexpr (K == 18) sa[0] = __builtin_amdgcn_raw_buffer_load_b128(asrc0, va, 0, 0);
+            else if constexpr (K == 19) sa[1] = __builtin_amdgcn_raw_buffer_load_b128(asrc1, va, 0, 0);
+            else if constexpr (K < 28) gf[gn][(K - 20) / 4][(K - 20) % 4] = lds_tr8<((K - 20) / 4) * Wg5::GPB + ((K - 20) % 4) * 32>(g_lo, g_hi);
+            else R[rm][(K - 28) / 2][(K - 28) % 2] = lds_tr8<((K - 28) % 2) * Wg5::APB>(aoff[(K - 28) / 2][0], aoff[(K - 28) / 2][1]);   // A(s + 2) into the slot row s - 1 has left
+        };
+        // slot: operations [LO, HI) and tap T (0 - 8; row = the ring slot of its dy)
+        auto slot = [&](auto lo, auto hi, auto tt) {
+            constexpr int LO = decltype(lo)::value, HI = decltype(hi)::value, T = decltype(tt)::value;
+            constexpr int NI = (HI > 20 ? HI - 20 : 0) - (LO > 20 ? LO - 20 : 0) + (HI - LO);   // instructions: a fragment is two reads
+            constexpr int RS = T / 3 == 0 ? rm : T / 3 == 1 ? r0 : rp;
+            __builtin_amdgcn_sched_barrier(0);
+            // (the taps that leave the board vertically are whole k-steps of zeros: skipped; their slots' memory operations are not)
+            if (T / 3 == 1 || (T / 3 == 0 ? y > 0 : y < Wg5::ROWS_Y - 1)) {
+                static_for<LO, HI>(op);
+                g5_tap<T>(R[RS][T % 3], gf[gc], acc);
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x0a0, 1, 0);   // one LDS or global-load instruction
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 12 - NI, 0);
+            } else {
+                asm volatile("; slot without its tap" ::: "memory");   // (keeps the two branches' common operations from being hoisted in front of the branch)
+                static_for<LO, HI>(op);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#define IC(n) std::integral_constant<int, n>{}
+        slot(IC(0), IC(6), IC(0)); slot(IC(6), IC(12), IC(1)); slot(IC(12), IC(18), IC(2));
+        slot(IC(18), IC(22), IC(3)); slot(IC(22), IC(25), IC(4)); slot(IC(25), IC(28), IC(5));
+        slot(IC(28), IC(31), IC(6)); slot(IC(31), IC(34), IC(7)); slot(IC(34), IC(34), IC(8));
+#undef IC
+        y = y == Wg5::ROWS_Y - 1 ? 0 : y + 1;
+    };
+    for (int s = 0; s < S; s += 6) {
+        kstep(std::integral_constant<int, 0>{}, s);
+        if (s + 1 < S) kstep(std::integral_constant<int, 1>{}, s + 1);
+        if (s + 2 < S) kstep(std::integral_constant<int, 2>{}, s + 2);
+        if (s + 3 < S) kstep(std::integral_constant<int, 3>{}, s + 3);
+        if (s + 4 < S) kstep(std::integral_constant<int, 4>{}, s + 4);
+        if (s + 5 < S) kstep(std::integral_constant<int, 5>{}, s + 5);
     }
     float* o = out + (size_t)slice * KC * NF;
 #pragma unroll
@@ -1963,12 +2213,14 @@ AZR_HOOK_FLAG g_gemm_bf16x3 = true;
 AZR_HOOK_FLAG g_fwd_f16 = true;
 constexpr float FWD_WSCALE = 1024.0f;   // the packed forward kernels are 2^10 * W: |w| < 64 stays inside fp16, a weight of 1e-4 keeps a normal low part
 AZR_HOOK_FLAG g_fuse_bwd = true;
+AZR_HOOK_FLAG g_wgrad_g5 = true;    // t_wgrad_g5 (k-step = a board row of five boards); AZR_TRAIN_WGRAD=rs: t_wgrad_rs (rows in memory order), the older formulation
 AZR_HOOK_FLAG g_conv_q = true;       // t_conv_q for batches of up to 128 records (AZR_TRAIN_CONVQ=0: t_conv_rs at every size)
 AZR_HOOK_FLAG g_fuse_apply = true;   // t_conv_rs<.., PRO>: the normalise kernels (t_bn_apply / t_bn_bwd_apply) computed in the consuming conv's staging path (AZR_TRAIN_FUSE_APPLY=0: separate kernels; same bits)   // t_conv_rs<2, 2, 1>: shortcut add + BN-backward stage 1 in the backward-data conv's epilogue (AZR_TRAIN_FUSE=0: separate kernels)
 
 struct TrainCtx {
     int BS = 0, blocks = 0, M = 0, L = 0, R = 0, nz = 0, kchunk = 0;
-    int wg_slices = 0, wg_rows = 0;          // t_wgrad_rs: row slices (split-K units of whole boards) and rows per slice
+    int wg_slices = 0, wg_rows = 0;          // weight gradient: slices (split-K units of whole boards) and rows per slice
+    int wg_bps = 0;                          // ... boards per slice
     size_t count = 0;
     long step = 0;
     float *g = nullptr, *m = nullptr, *v = nullptr;
@@ -1994,7 +2246,7 @@ struct TrainCtx {
     double* red = nullptr;     // [2 * NG][256] reduced BN partials
     double* hsum = nullptr;    // [6] head BN sums
     float* lr = nullptr;   // device: this step's bias-corrected learning rate
-    // the weight-gradient branch of the backward pass (t_wgrad_rs + t_sum_slices of every layer) hangs off the gradient chain: nothing
+    // the weight-gradient branch of the backward pass (t_wgrad_g5 + t_sum_slices of every layer) hangs off the gradient chain: nothing
     // but Adam waits for it.  At small batches (<= 128 records: a rank's share of a data-parallel minibatch) it runs on a second,
     // low-priority stream beside the chain's kernels, which leave most of the chip idle there: 4.22 -> 3.87 ms per step at 64 records.
     hipStream_t side = nullptr;
@@ -2037,6 +2289,18 @@ void ctx_free(TrainCtx* c)
         if (rc__) return rc__; \
     } while (0)
 
+// the weight gradient of one tower conv: 64 one-wave blocks (16 ci tiles x 4 co quarters) per slice of whole boards -> c->wpart[slice]
+static void launch_wgrad(TrainCtx* c, hipStream_t st, const Parts& apP, const Parts& dyP, int M)
+{
+#ifdef AZR_TEST_HOOKS
+    if (!g_wgrad_g5) {
+        hipLaunchKernelGGL(t_wgrad_rs, dim3(64 * c->wg_slices), dim3(64), Wg::LDS_BYTES, st, apP, dyP, c->wpart, M, c->wg_slices, c->wg_rows);
+        return;
+    }
+#endif
+    hipLaunchKernelGGL(t_wgrad_g5, dim3(64 * c->wg_slices), dim3(64), Wg5::LDS_BYTES, st, apP, dyP, c->wpart, M / NPOS, c->wg_slices, c->wg_bps);
+}
+
 int ctx_ensure(azr_engine* h, int BS)
 {
     TrainCtx* c = ctx_of(h);
@@ -2048,8 +2312,12 @@ int ctx_ensure(azr_engine* h, int BS)
     g_fwd_f16 = !(hook_env("AZR_TRAIN_FWD") && strcmp(hook_env("AZR_TRAIN_FWD"), "bf16") == 0);
     g_fuse_apply = hook_env_int("AZR_TRAIN_FUSE_APPLY", 1) != 0;
     g_conv_q = hook_env_int("AZR_TRAIN_CONVQ", 1) != 0;
+    g_wgrad_g5 = !(hook_env("AZR_TRAIN_WGRAD") && strcmp(hook_env("AZR_TRAIN_WGRAD"), "rs") == 0);
 #endif
+#ifdef AZR_TEST_HOOKS
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(t_wgrad_rs), hipFuncAttributeMaxDynamicSharedMemorySize, Wg::LDS_BYTES));
+#endif
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(t_wgrad_g5), hipFuncAttributeMaxDynamicSharedMemorySize, Wg5::LDS_BYTES));
     // a different batch size rebuilds the activation slabs but keeps the optimiser state
     std::vector<float> keep_m, keep_v;
     long keep_step = 0;
@@ -2084,9 +2352,12 @@ int ctx_ensure(azr_engine* h, int BS)
     // t_wgrad_rs: slices of 16 j boards (16 boards = 672 rows = 21 k-steps), about 256 blocks = 16 ci tiles x slices
     {
         // (small batches — a rank's share of a data-parallel minibatch: 8-board slices, so that 64 records are 512 one-wave blocks)
-        const int bps = (BS <= 128 && BS % 8 == 0) ? 8 : 16 * std::max(1, BS / 256);
+        int bps = (BS <= 128 && BS % 8 == 0) ? 8 : 16 * std::max(1, BS / 256);
+        // t_wgrad_g5: whole groups of 5 boards, about 16 slices (x 64 one-wave blocks = the chip's 1024 SIMDs): 512 records = 15 slices of 35
+        if (g_wgrad_g5) bps = std::max(Wg5::GB, ((BS + 15) / 16 + Wg5::GB - 1) / Wg5::GB * Wg5::GB);
         c->wg_slices = (BS + bps - 1) / bps;
         c->wg_rows = bps * NPOS;
+        c->wg_bps = bps;
     }
     TRY(dalloc(h, c, &c->wpart, (size_t)std::max(c->nz, c->wg_slices) * KC * NF));
     // bf16 parts of the post-activations: the two leading parts are kept PER LAYER (the weight-gradient GEMM of the backward
@@ -2392,14 +2663,14 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
                             // VGPRs: no SIMD holds a wave of both) and nothing overlaps: one stream.  (Measured at batch 512: the branch on the
                             // side stream 11.16 ms per step, only its slice sums there 11.28, one stream 11.1 — a cross-stream edge costs the
                             // chain a barrier packet per layer, about what hiding the 10-us slice sum saves.)
-                hipLaunchKernelGGL(t_wgrad_rs, dim3(64 * c->wg_slices), dim3(64), Wg::LDS_BYTES, st, apP, dyP, c->wpart, M, c->wg_slices, c->wg_rows);
+                launch_wgrad(c, st, apP, dyP, M);
                 pending_sum = Gl(l);   // summed by the next layer's launch (t_sum_slices_fin), or behind the loop
                 continue;
             }
             // small batches (a rank's share of a data-parallel minibatch): the chain's kernels leave most of the chip idle, the branch runs beside them
             HIPCHK(h, hipEventRecord(c->ev_conv[q], st));
             HIPCHK(h, hipStreamWaitEvent(c->side, c->ev_conv[q], 0));
-            hipLaunchKernelGGL(t_wgrad_rs, dim3(64 * c->wg_slices), dim3(64), Wg::LDS_BYTES, c->side, apP, dyP, c->wpart, M, c->wg_slices, c->wg_rows);
+            launch_wgrad(c, c->side, apP, dyP, M);
             hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, c->side, c->wpart, c->wg_slices, wn, Gl(l));
             HIPCHK(h, hipEventRecord(c->ev_wg[q], c->side));
             side_used |= 1 << q;
@@ -2414,7 +2685,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         //  GEMMs.  The split-bf16 kernels WITHOUT the staging-path fusions are older formulations, compiled into libazr_hip_test.so only.)
 #ifdef AZR_TEST_HOOKS
         if (sb) {
-            hipLaunchKernelGGL(t_wgrad_rs, dim3(64 * c->wg_slices), dim3(64), Wg::LDS_BYTES, st, apP, dyP, c->wpart, M, c->wg_slices, c->wg_rows);
+            launch_wgrad(c, st, apP, dyP, M);
         } else
 #endif
         gemm<true, false, 128, 1, 0>(st, Al(l - 1), KC, c->dY, NF, c->wpart, NF, KC, NF, M, c->nz, c->kchunk, wn);
@@ -2702,3 +2973,4 @@ extern "C" int azr_nn_train_reset(azr_engine* h)
     azr::train_free(h);
     return AZR_OK;
 }
+

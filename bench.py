@@ -243,7 +243,7 @@ def arena_leg(pkg, blocks, games=100, slots=128, sims=100, threads=2):
             "tower_fallbacks": fb,
             "what": "two-net arena, 50 mirrored pairs: `wall_s` with a pair's two games at the same time on two slots (100 slots busy), "
                     "`sequential_wall_s` with each pair's games one after the other on one slot (the reference's thread-per-pair form); "
-                    "launches of <= 128 leaves (k_tower_sc)"}
+                    "passes queued without a read-back; k_tower_sc while both nets' launches fit the CUs, one board per workgroup otherwise"}
 
 
 def run_config(ctx, games, sims, threads, steps, warmup, tail, dtype=None, midgame=False):

@@ -107,7 +107,7 @@ def test_step_matches_torch_graph(blocks, bs, gemm, monkeypatch):
     paths and epilogues; "r2": the same kernels as round 2 ran them (6-pass bf16 forward, separate normalise kernels:
     AZR_TRAIN_FWD=bf16, AZR_TRAIN_FUSE=0); "f32": the fp32-MFMA GEMMs
     (AZR_TRAIN_GEMM=f32); batch 10 (42 * 10 rows, not a multiple of the 32-deep k-tile) takes the fp32 kernels by itself.  Batches of up to 128 records run the small-batch
-    conv kernel (t_conv_q) and 8-board weight-gradient slices."""
+    conv kernel (t_conv_q) and 5-board weight-gradient slices."""
     for k in ("AZR_TRAIN_GEMM", "AZR_TRAIN_FWD", "AZR_TRAIN_FUSE", "AZR_TRAIN_FUSE_APPLY"):
         monkeypatch.delenv(k, raising=False)
     if gemm == "f32":
@@ -214,7 +214,7 @@ def test_step_on_unfiltered_records(blocks, bs):
 
 
 def test_conv_kernel_families_at_the_reference_batch(monkeypatch):
-    """BATCH_SIZE 512 (the reference's; 256 two-board blocks of t_conv_rs, 16 row slices of 42 k-steps of t_wgrad_rs — the
+    """BATCH_SIZE 512 (the reference's; 256 two-board blocks of t_conv_rs, 15 slices of 7 five-board groups of t_wgrad_g5 — the
     shapes the learn loop runs): one step with the default kernels (fp16-pair forward, fused normalise / statistics), one as
     round 2 ran them (6-pass bf16 forward, separate kernels) and one with the fp32-MFMA GEMMs, against the float64 PyTorch
     graph.  With 27 M ReLU inputs per step some lie within fp32 rounding of zero (2.9e-8 here) and every implementation flips
@@ -246,6 +246,37 @@ def test_conv_kernel_families_at_the_reference_batch(monkeypatch):
             n = int(np.prod(shape))
             err = np.linalg.norm(g[off:off + n] - rg[off:off + n]) / np.linalg.norm(rg[off:off + n])
             assert err <= (3e-3 if name[0] in "sb" else 1e-5), (mode, name, err)   # stem / block kernels | head tensors
+
+
+@pytest.mark.parametrize("bs", [512, 64, 48, 16])
+def test_weight_gradient_formulations_agree(monkeypatch, bs):
+    """t_wgrad_g5 (the product: a k-step is one board row of five boards, the taps share fragments out of a ring of three rows, slices of
+    whole groups) against t_wgrad_rs (rows in memory order, one fragment read per tap; libazr_hip_test.so, AZR_TRAIN_WGRAD=rs): the same
+    products summed in another order — identical losses, conv-kernel gradients to fp32 summation noise.  48 and 16 records end in a
+    partial group of boards (48 = 9 slices of 5 + 3, 16 = 3 x 5 + 1)."""
+    P = pkg()
+    blocks = 2
+    flat = T.make_net_flat(blocks, seed=21, perturb_bn=True)
+    rec = records(bs, seed=77)
+    out = {}
+    for mode in ("g5", "rs"):
+        monkeypatch.delenv("AZR_TRAIN_WGRAD", raising=False)
+        if mode == "rs":
+            monkeypatch.setenv("AZR_TRAIN_WGRAD", "rs")
+        eng = P.Engine(8, blocks=blocks, sims=1, dtype=P.NET_F32, node_capacity=64, test_hooks=mode == "rs")
+        eng.set_weights(flat)
+        out[mode] = (eng.train_batch(rec), eng.train_grads().astype(np.float64))
+        eng.close()
+    assert out["g5"][0] == out["rs"][0]
+    a, b = out["g5"][1], out["rs"][1]
+    for name, off, shape in train.layout(blocks)[0]:
+        n = int(np.prod(shape)) if not name.endswith("_bn") else 2 * shape[1]
+        x, y = a[off:off + n], b[off:off + n]
+        if name.startswith("b") and name.endswith("_w"):
+            err = np.linalg.norm(x - y) / np.linalg.norm(y)
+            assert 0 < err <= 2e-6, (name, err)   # (0 would mean the switch did nothing)
+        else:
+            assert (x == y).all(), name           # everything else runs the same kernels on the same bits
 
 
 def test_steps_are_reproducible_and_adam_state_persists():
