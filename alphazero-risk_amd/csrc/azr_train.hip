@@ -1287,66 +1287,68 @@ __device__ __forceinline__ void static_for(F&& f)
         static_for<I + 1, N>(f);
     }
 }
+template <int NC>   // NC = co tiles of 16 per wave: 4 (64 output channels, 64 blocks per slice) or 2 (32 channels, 128 blocks per slice)
 struct Wg5 {
     static constexpr int GB = 5, KR = 32, ROWS_Y = 7;
     static constexpr int AST = 32;                                     // bytes per row of the A tile (16 ci)
     __host__ __device__ static constexpr int arow(int r) { return r * AST + (r >> 3) * 128; }   // rows 0 .. 31, row 32 = the zero row
     static constexpr int APB = 33 * AST + 5 * 128;
-    static constexpr int GST = 160;
+    // dY tile rows: NC x 32 bytes + pad so that the pitch is 8 banks mod 16 — with 32 banks in front of every further group of 8 rows the
+    // eight rows of a transposed read (r .. r + 3 and r + 8 .. r + 11, 8 banks each) cover the 64 banks once (40 banks / 24 banks)
+    static constexpr int GST = NC == 4 ? 160 : 96;
     __host__ __device__ static constexpr int grow(int r) { return r * GST + (r >> 3) * 128; }
     static constexpr int GPB = KR * GST + (KR / 8) * 128;
     static constexpr int LDS_BYTES = 2 * APB + 2 * GPB;               // A part 0 | A part 1 | dY part 0 | dY part 1
+    static constexpr int COW = 16 * NC;                                // output channels per wave
+    static constexpr int BLOCKS_PER_SLICE = 16 * (NF / COW);
+    // the memory operations of a k-step, in dependence order: tile stores (GU dY units x 2 parts, 2 A units), global loads (the same
+    // units), dY fragments (2 parts x NC, two reads each), A fragments (3 dx x 2 parts, two reads each)
+    static constexpr int GU = NC;                                      // 16-byte dY units per lane and part (32 rows x 2 NC segments / 64 lanes)
+    static constexpr int NW = 2 * GU + 2, NL = 2 * GU + 2, NG = 2 * NC, NA = 6, NOPS = NW + NL + NG + NA;
+    static constexpr int BUDGET = NC == 4 ? 6 : 4;                     // memory instructions dealt into one tap's slot (3 NC MFMAs)
+    __host__ __device__ static constexpr int cost(int k) { return k < NW + NL ? 1 : 2; }
+    __host__ __device__ static constexpr int slot_lo(int slot)          // first operation of a slot: greedy fill in order
+    {
+        int k = 0;
+        for (int sl = 0; sl < slot; sl++) {
+            int b = 0;
+            while (k < NOPS && b + cost(k) <= BUDGET) { b += cost(k); k++; }
+        }
+        return k;
+    }
+    static_assert(slot_lo(9) == NOPS, "nine slots take every operation");
+    static_assert(slot_lo(3) <= NW + NL + NG, "the A fragment reads stand behind the dy = -1 taps (slots 0 - 2)");
 };
 
-template <int T>
-__device__ __forceinline__ void g5_tap(const s16x8 (&a)[2], const s16x8 (&gf)[2][4], f32x4 (&acc)[9][4])
+template <int T, int NC>
+__device__ __forceinline__ void g5_tap(const s16x8 (&a)[2], const s16x8 (&gf)[2][NC], f32x4 (&acc)[9][NC])
 {
 #pragma unroll
-    for (int c = 0; c < 4; c++)
+    for (int c = 0; c < NC; c++)
         acc[T][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, gf[0][c]), acc[T][c], 0, 0, 0);
 #pragma unroll
-    for (int c = 0; c < 4; c++)
+    for (int c = 0; c < NC; c++)
         acc[T][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, gf[1][c]), acc[T][c], 0, 0, 0);
 #pragma unroll
-    for (int c = 0; c < 4; c++)
+    for (int c = 0; c < NC; c++)
         acc[T][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, gf[0][c]), acc[T][c], 0, 0, 0);
 }
-// the three taps of one dy: row fragments r[dx][part] against the k-step's dY fragments
-template <int DY>
-__device__ __forceinline__ void g5_taps(const s16x8 (&r)[3][2], const s16x8 (&gf)[2][4], f32x4 (&acc)[9][4])
-{
-    g5_tap<(DY + 1) * 3 + 0>(r[0], gf, acc);
-    g5_tap<(DY + 1) * 3 + 1>(r[1], gf, acc);
-    g5_tap<(DY + 1) * 3 + 2>(r[2], gf, acc);
-}
-__device__ __forceinline__ void g5_read_g(uint32_t g_lo, uint32_t g_hi, s16x8 (&gf)[2][4])
-{
-    gf[0][0] = lds_tr8<0>(g_lo, g_hi); gf[0][1] = lds_tr8<32>(g_lo, g_hi); gf[0][2] = lds_tr8<64>(g_lo, g_hi); gf[0][3] = lds_tr8<96>(g_lo, g_hi);
-    gf[1][0] = lds_tr8<Wg5::GPB>(g_lo, g_hi); gf[1][1] = lds_tr8<Wg5::GPB + 32>(g_lo, g_hi);
-    gf[1][2] = lds_tr8<Wg5::GPB + 64>(g_lo, g_hi); gf[1][3] = lds_tr8<Wg5::GPB + 96>(g_lo, g_hi);
-}
-__device__ __forceinline__ void g5_read_a(const uint32_t (&aoff)[3][2], s16x8 (&r)[3][2])
-{
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        r[d][0] = lds_tr8<0>(aoff[d][0], aoff[d][1]);
-        r[d][1] = lds_tr8<Wg5::APB>(aoff[d][0], aoff[d][1]);
-    }
-}
 
+template <int NC>
 __global__ __launch_bounds__(64, 1) void t_wgrad_g5(Parts A, Parts G, float* __restrict__ out, int boards, int NS, int boards_per_slice)
 {
+    using W = Wg5<NC>;
     extern __shared__ __attribute__((aligned(16))) uint8_t wg_lds[];
     const int lane = threadIdx.x;
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
-    const int slice = blockIdx.x % NS, rest = blockIdx.x / NS, cit = rest & 15, wq = rest >> 4;   // wq = which 64 co columns
+    const int slice = blockIdx.x % NS, rest = blockIdx.x / NS, cit = rest & 15, wq = rest >> 4;   // wq = which COW output channels
     const int bbeg = slice * boards_per_slice, bend = min(boards, bbeg + boards_per_slice);
-    const int S = Wg5::ROWS_Y * ((bend - bbeg + Wg5::GB - 1) / Wg5::GB);   // k-steps of the slice
+    const int S = W::ROWS_Y * ((bend - bbeg + W::GB - 1) / W::GB);   // k-steps of the slice
 
-    if (lane < 2 * (Wg5::AST / 4))   // zero rows of the two A parts
-        reinterpret_cast<uint32_t*>(wg_lds + (lane / (Wg5::AST / 4)) * Wg5::APB + Wg5::arow(32))[lane % (Wg5::AST / 4)] = 0u;
+    if (lane < 2 * (W::AST / 4))   // zero rows of the two A parts
+        reinterpret_cast<uint32_t*>(wg_lds + (lane / (W::AST / 4)) * W::APB + W::arow(32))[lane % (W::AST / 4)] = 0u;
 
-    // Staging units of this lane: 8 of the dY tile (4 (tile row, 16-byte segment) pairs x 2 parts) and 2 of the A tile (one per part).
+    // Staging units of this lane: GU of the dY tile per part ((tile row, 16-byte segment) pairs) and one of the A tile per part.
     // Tile row k = board 6 j + column x of the group; rows 30, 31 and the boards past the slice are out of range of the buffer resources
     // (everything is in the vector offset, which the range check sees) and arrive as zeros.
     const uint32_t range = (uint32_t)bend * NPOS * NF * 2u;
@@ -1355,156 +1357,136 @@ __global__ __launch_bounds__(64, 1) void t_wgrad_g5(Parts A, Parts G, float* __r
     const __amdgpu_buffer_rsrc_t asrc0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A.p[0]), (short)0, range, 0x00020000);
     const __amdgpu_buffer_rsrc_t asrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A.p[1]), (short)0, range, 0x00020000);
     constexpr uint32_t OOR = 0xfffffff0u;
-    uint32_t gvo[4], gl[4], avo, al;
+    constexpr int SEGS = 2 * NC;   // 16-byte segments of a dY tile row
+    uint32_t gvo[W::GU], gl[W::GU], avo, al;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int k = i * 8 + (lane >> 3), seg = lane & 7;
-        gvo[i] = k < 30 ? (uint32_t)((((bbeg + k / 6) * NPOS + k % 6) * NF + wq * 64 + seg * 8) * 2) : OOR;
-        gl[i] = (uint32_t)(2 * Wg5::APB + Wg5::grow(k) + seg * 16);
+    for (int i = 0; i < W::GU; i++) {
+        const int u = lane + 64 * i, k = u / SEGS, seg = u % SEGS;
+        gvo[i] = k < 30 ? (uint32_t)((((bbeg + k / 6) * NPOS + k % 6) * NF + wq * W::COW + seg * 8) * 2) : OOR;
+        gl[i] = (uint32_t)(2 * W::APB + W::grow(k) + seg * 16);
     }
     {
         const int k = lane >> 1, seg = lane & 1;
         avo = k < 30 ? (uint32_t)((((bbeg + k / 6) * NPOS + k % 6) * NF + cit * 16 + seg * 8) * 2) : OOR;
-        al = (uint32_t)(Wg5::arow(k) + seg * 16);
+        al = (uint32_t)(W::arow(k) + seg * 16);
     }
     // byte offset of flat k-step s: group s / 7 (5 boards further each), board row s % 7
-    auto step_off = [](int s) -> uint32_t { return (uint32_t)(((s / Wg5::ROWS_Y) * Wg5::GB * NPOS + (s % Wg5::ROWS_Y) * 6) * NF * 2); };
-    u32x4 sg[8], sa[2];
-    auto fetch_g = [&](int s) {
-        const uint32_t so = step_off(s);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t vo = gvo[i] == OOR ? OOR : gvo[i] + so;
-            sg[i] = __builtin_amdgcn_raw_buffer_load_b128(gsrc0, vo, 0, 0);
-            sg[i + 4] = __builtin_amdgcn_raw_buffer_load_b128(gsrc1, vo, 0, 0);
-        }
-    };
-    auto fetch_a = [&](int s) {
-        const uint32_t vo = avo == OOR ? OOR : avo + step_off(s);
-        sa[0] = __builtin_amdgcn_raw_buffer_load_b128(asrc0, vo, 0, 0);
-        sa[1] = __builtin_amdgcn_raw_buffer_load_b128(asrc1, vo, 0, 0);
-    };
-    auto stash_g = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            *reinterpret_cast<u32x4*>(wg_lds + gl[i]) = sg[i];
-            *reinterpret_cast<u32x4*>(wg_lds + Wg5::GPB + gl[i]) = sg[i + 4];
-        }
-    };
-    auto stash_a = [&]() {
-        *reinterpret_cast<u32x4*>(wg_lds + al) = sa[0];
-        *reinterpret_cast<u32x4*>(wg_lds + Wg5::APB + al) = sa[1];
-    };
+    auto step_off = [](int s) -> uint32_t { return (uint32_t)(((s / W::ROWS_Y) * W::GB * NPOS + (s % W::ROWS_Y) * 6) * NF * 2); };
+    u32x4 sg[2 * W::GU], sa[2];
 
     // the two tile rows this lane addresses in a transposed read (k1 = 8 g + q and k1 + 4), their columns, and per dx the LDS address of
     // the source row: k + dx inside the board row, the zero row outside it (and for the idle k = 30, 31)
     const int k1 = 8 * g + q, k2 = k1 + 4;
     const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)wg_lds;
-    const uint32_t a_zero = lbase + (uint32_t)(Wg5::arow(32) + p * 8);
+    const uint32_t a_zero = lbase + (uint32_t)(W::arow(32) + p * 8);
     uint32_t aoff[3][2];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
         const int x1 = k1 % 6 + d - 1, x2 = k2 % 6 + d - 1;
-        aoff[d][0] = (k1 < 30 && x1 >= 0 && x1 < 6) ? lbase + (uint32_t)(Wg5::arow(k1 + d - 1) + p * 8) : a_zero;
-        aoff[d][1] = (k2 < 30 && x2 >= 0 && x2 < 6) ? lbase + (uint32_t)(Wg5::arow(k2 + d - 1) + p * 8) : a_zero;
+        aoff[d][0] = (k1 < 30 && x1 >= 0 && x1 < 6) ? lbase + (uint32_t)(W::arow(k1 + d - 1) + p * 8) : a_zero;
+        aoff[d][1] = (k2 < 30 && x2 >= 0 && x2 < 6) ? lbase + (uint32_t)(W::arow(k2 + d - 1) + p * 8) : a_zero;
     }
-    const uint32_t g_lo = lbase + (uint32_t)(2 * Wg5::APB + Wg5::grow(k1) + p * 8);
-    const uint32_t g_hi = lbase + (uint32_t)(2 * Wg5::APB + Wg5::grow(k2) + p * 8);
+    const uint32_t g_lo = lbase + (uint32_t)(2 * W::APB + W::grow(k1) + p * 8);
+    const uint32_t g_hi = lbase + (uint32_t)(2 * W::APB + W::grow(k2) + p * 8);
 
-    f32x4 acc[9][4];
+    f32x4 acc[9][NC];
 #pragma unroll
     for (int t = 0; t < 9; t++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    s16x8 R[3][3][2];    // A fragments [ring slot = board-row index mod 3][dx][part]
-    s16x8 gf[2][2][4];   // dY fragments [k-step mod 2][part][co tile]
+        for (int c = 0; c < NC; c++) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    s16x8 R[3][3][2];     // A fragments [ring slot = board-row index mod 3][dx][part]
+    s16x8 gf[2][2][NC];   // dY fragments [k-step mod 2][part][co tile]
 
+    // Operation K of a k-step that stores tile TS + 1, requests tile TS + 2 (vg, va: its vector offsets), reads the dY fragments into gf[GN]
+    // and the A fragments into ring slot RM:  tile stores | global loads | dY fragments | A fragments (Wg5: NW, NL, NG, NA)
+    uint32_t vg[W::GU], va = OOR;
+    auto op = [&](auto kk, auto gnn, auto rmm) {
+        constexpr int K = decltype(kk)::value, GN = decltype(gnn)::value, RM = decltype(rmm)::value;
+        constexpr int KW = K, KL = K - W::NW, KG = K - W::NW - W::NL, KA = K - W::NW - W::NL - W::NG;
+        if constexpr (KW < W::GU) *reinterpret_cast<u32x4*>(wg_lds + gl[KW]) = sg[KW];
+        else if constexpr (KW < 2 * W::GU) *reinterpret_cast<u32x4*>(wg_lds + W::GPB + gl[KW - W::GU]) = sg[KW];
+        else if constexpr (KW == 2 * W::GU) *reinterpret_cast<u32x4*>(wg_lds + al) = sa[0];
+        else if constexpr (KW == 2 * W::GU + 1) *reinterpret_cast<u32x4*>(wg_lds + W::APB + al) = sa[1];
+        else if constexpr (KL < W::GU) sg[KL] = __builtin_amdgcn_raw_buffer_load_b128(gsrc0, vg[KL], 0, 0);
+        else if constexpr (KL < 2 * W::GU) sg[KL] = __builtin_amdgcn_raw_buffer_load_b128(gsrc1, vg[KL - W::GU], 0, 0);
+        else if constexpr (KL == 2 * W::GU) sa[0] = __builtin_amdgcn_raw_buffer_load_b128(asrc0, va, 0, 0);
+        else if constexpr (KL == 2 * W::GU + 1) sa[1] = __builtin_amdgcn_raw_buffer_load_b128(asrc1, va, 0, 0);
+        else if constexpr (KG < W::NG) gf[GN][KG / NC][KG % NC] = lds_tr8<(KG / NC) * W::GPB + (KG % NC) * 32>(g_lo, g_hi);
+        else R[RM][KA / 2][KA % 2] = lds_tr8<(KA % 2) * W::APB>(aoff[KA / 2][0], aoff[KA / 2][1]);
+    };
+    auto offsets = [&](int sd, int sa_) {   // vector offsets of the loads of {dY(sd), A(sa_)}
+        const uint32_t so_g = step_off(sd), so_a = step_off(sa_);
+#pragma unroll
+        for (int i = 0; i < W::GU; i++) vg[i] = gvo[i] == OOR ? OOR : gvo[i] + so_g;
+        va = avo == OOR ? OOR : avo + so_a;
+    };
+#define IC(n) std::integral_constant<int, (n)>{}
     // prologue: A(0) -> ring slot 0; tile 0 = {dY(0), A(1)} -> gf[0], ring slot 1; tile 1 on its way
-    fetch_a(0);
-    stash_a();
+    offsets(0, 0);
+    op(IC(W::NW + 2 * W::GU), IC(0), IC(0)); op(IC(W::NW + 2 * W::GU + 1), IC(0), IC(0));                   // load A(0)
+    op(IC(2 * W::GU), IC(0), IC(0)); op(IC(2 * W::GU + 1), IC(0), IC(0));                                   // store it
     asm volatile("" ::: "memory");
-    g5_read_a(aoff, R[0]);
-    fetch_g(0); fetch_a(1);
+    static_for<W::NW + W::NL + W::NG, W::NOPS>([&](auto k) { op(k, IC(0), IC(0)); });                       // -> R[0]
+    offsets(0, 1);
+    static_for<W::NW, W::NW + W::NL>([&](auto k) { op(k, IC(0), IC(0)); });                                 // load tile 0
     asm volatile("" ::: "memory");
-    stash_g(); stash_a();
+    static_for<0, W::NW>([&](auto k) { op(k, IC(0), IC(0)); });                                             // store it
     asm volatile("" ::: "memory");
-    g5_read_g(g_lo, g_hi, gf[0]);
-    g5_read_a(aoff, R[1]);
-    fetch_g(1); fetch_a(2);
+    static_for<W::NW + W::NL, W::NOPS>([&](auto k) { op(k, IC(0), IC(1)); });                               // -> gf[0], R[1]
+    offsets(1, 2);
+    static_for<W::NW, W::NW + W::NL>([&](auto k) { op(k, IC(0), IC(0)); });                                 // load tile 1
 
-    // One k-step = one straight-line piece of code per (ring phase, board edge), cut into SLOTS of one tap (12 MFMAs) each.  The 48 memory
-    // instructions of the k-step — 10 tile stores, 10 global loads, 16 dY fragment reads, 12 A fragment reads — are dealt over the slots
-    // (6 per slot of a nine-tap k-step, 8 of a six-tap one) and inside a slot one is issued behind each of the first MFMAs
+    // One k-step = one straight-line piece of code per ring phase, cut into SLOTS of one tap (3 NC MFMAs) each.  The memory instructions of
+    // the k-step are dealt over the slots in dependence order (Wg5::slot_lo) and inside a slot one is issued behind each of the first MFMAs
     // (sched_group_barrier; a slot is one scheduling region): a lone wave issues in order, and ten stores or sixteen reads in a row in
     // front of the MFMAs leave the matrix pipe idle for as long as they take to issue.
-    // Operation k of a k-step: 0 - 9 tile stores (W), 10 - 19 global loads (F), 20 - 27 dY fragments (two reads each), 28 - 33 A fragments.
     int y = 0;
     auto kstep = [&](auto ph, int s) {
         constexpr int PH = decltype(ph)::value;
         constexpr int rm = (PH + 2) % 3, r0 = PH % 3, rp = (PH + 1) % 3, gc = PH % 2, gn = (PH + 1) % 2;
-        const uint32_t so_g = step_off(s + 2), so_a = step_off(s + 3);   // tile s + 2 = {dY(s + 2), A(s + 3)} (zeros past the slice: nobody multiplies them)
-        uint32_t vg[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) vg[i] = gvo[i] == OOR ? OOR : gvo[i] + so_g;
-        const uint32_t va = avo == OOR ? OOR : avo + so_a;
-        auto op = [&](auto kk) {
-            constexpr int K = decltype(kk)::value;
-            if constexpr (K < 4) *reinterpret_cast<u32x4*>(wg_lds + gl[K]) = sg[K];                        // tile s + 1 = {dY(s + 1), A(s + 2)} over tile s:
-            else if constexpr (K < 8) *reinterpret_cast<u32x4*>(wg_lds + Wg5::GPB + gl[K - 4]) = sg[K];    // every read of tile s was issued in k-step s - 1
-            else if constexpr (K == 8) *reinterpret_cast<u32x4*>(wg_lds + al) = sa[0];
-            else if constexpr (K == 9) *reinterpret_cast<u32x4*>(wg_lds + Wg5::APB + al) = sa[1];
-            else if constexpr (K < 14) sg[K - 10] = __builtin_amdgcn_raw_buffer_load_b128(gsrc0, vg[K - 10], 0, 0);
-            else if constexpr (K < 18) sg[K - 10] = __builtin_amdgcn_raw_buffer_load_b128(gsrc1, vg[K - 14], 0, 0);
-            else if constexpr (K == 18) sa[0] = __builtin_amdgcn_raw_buffer_load_b128(asrc0, va, 0, 0);
-            else if constexpr (K == 19) sa[1] = __builtin_amdgcn_raw_buffer_load_b128(asrc1, va, 0, 0);
-            else if constexpr (K < 28) gf[gn][(K - 20) / 4][(K - 20) % 4] = lds_tr8<((K - 20) / 4) * Wg5::GPB + ((K - 20) % 4) * 32>(g_lo, g_hi);
-            else R[rm][(K - 28) / 2][(K - 28) % 2] = lds_tr8<((K - 28) % 2) * Wg5::APB>(aoff[(K - 28) / 2][0], aoff[(K - 28) / 2][1]);   // A(s + 2) into the slot row s - 1 has left
-        };
-        // slot: operations [LO, HI) and tap T (0 - 8; row = the ring slot of its dy)
-        auto slot = [&](auto lo, auto hi, auto tt) {
-            constexpr int LO = decltype(lo)::value, HI = decltype(hi)::value, T = decltype(tt)::value;
-            constexpr int NI = (HI > 20 ? HI - 20 : 0) - (LO > 20 ? LO - 20 : 0) + (HI - LO);   // instructions: a fragment is two reads
+        offsets(s + 2, s + 3);   // tile s + 2 = {dY(s + 2), A(s + 3)} (past the slice: zeros or the next slice's rows — nobody multiplies them)
+        auto slot = [&](auto tt) {
+            constexpr int T = decltype(tt)::value, LO = W::slot_lo(T), HI = W::slot_lo(T + 1);
+            constexpr int NI = []() { int n = 0; for (int k = LO; k < HI; k++) n += W::cost(k); return n; }();
             constexpr int RS = T / 3 == 0 ? rm : T / 3 == 1 ? r0 : rp;
+            auto ops = [&](auto k) { op(k, IC(gn), IC(rm)); };   // (the A fragments: A(s + 2) into the slot row s - 1 has left)
             __builtin_amdgcn_sched_barrier(0);
             // (the taps that leave the board vertically are whole k-steps of zeros: skipped; their slots' memory operations are not)
-            if (T / 3 == 1 || (T / 3 == 0 ? y > 0 : y < Wg5::ROWS_Y - 1)) {
-                static_for<LO, HI>(op);
-                g5_tap<T>(R[RS][T % 3], gf[gc], acc);
+            if (T / 3 == 1 || (T / 3 == 0 ? y > 0 : y < W::ROWS_Y - 1)) {
+                static_for<LO, HI>(ops);
+                g5_tap<T, NC>(R[RS][T % 3], gf[gc], acc);
 #pragma unroll
                 for (int i = 0; i < NI; i++) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
                     __builtin_amdgcn_sched_group_barrier(0x0a0, 1, 0);   // one LDS or global-load instruction
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 12 - NI, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NC - NI, 0);
             } else {
                 asm volatile("; slot without its tap" ::: "memory");   // (keeps the two branches' common operations from being hoisted in front of the branch)
-                static_for<LO, HI>(op);
+                static_for<LO, HI>(ops);
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-#define IC(n) std::integral_constant<int, n>{}
-        slot(IC(0), IC(6), IC(0)); slot(IC(6), IC(12), IC(1)); slot(IC(12), IC(18), IC(2));
-        slot(IC(18), IC(22), IC(3)); slot(IC(22), IC(25), IC(4)); slot(IC(25), IC(28), IC(5));
-        slot(IC(28), IC(31), IC(6)); slot(IC(31), IC(34), IC(7)); slot(IC(34), IC(34), IC(8));
-#undef IC
-        y = y == Wg5::ROWS_Y - 1 ? 0 : y + 1;
+        static_for<0, 9>(slot);
+        y = y == W::ROWS_Y - 1 ? 0 : y + 1;
     };
     for (int s = 0; s < S; s += 6) {
-        kstep(std::integral_constant<int, 0>{}, s);
-        if (s + 1 < S) kstep(std::integral_constant<int, 1>{}, s + 1);
-        if (s + 2 < S) kstep(std::integral_constant<int, 2>{}, s + 2);
-        if (s + 3 < S) kstep(std::integral_constant<int, 3>{}, s + 3);
-        if (s + 4 < S) kstep(std::integral_constant<int, 4>{}, s + 4);
-        if (s + 5 < S) kstep(std::integral_constant<int, 5>{}, s + 5);
+        kstep(IC(0), s);
+        if (s + 1 < S) kstep(IC(1), s + 1);
+        if (s + 2 < S) kstep(IC(2), s + 2);
+        if (s + 3 < S) kstep(IC(3), s + 3);
+        if (s + 4 < S) kstep(IC(4), s + 4);
+        if (s + 5 < S) kstep(IC(5), s + 5);
     }
+#undef IC
     float* o = out + (size_t)slice * KC * NF;
 #pragma unroll
     for (int t = 0; t < 9; t++)
 #pragma unroll
-        for (int c = 0; c < 4; c++)
+        for (int c = 0; c < NC; c++)
 #pragma unroll
             for (int e = 0; e < 4; e++)
-                o[(size_t)(t * NF + cit * 16 + 4 * g + e) * NF + wq * 64 + c * 16 + i16] = acc[t][c][e];
+                o[(size_t)(t * NF + cit * 16 + 4 * g + e) * NF + wq * W::COW + c * 16 + i16] = acc[t][c][e];
 }
 
 // out[i] = sum_z part[z][i]
@@ -2213,6 +2195,9 @@ AZR_HOOK_FLAG g_gemm_bf16x3 = true;
 AZR_HOOK_FLAG g_fwd_f16 = true;
 constexpr float FWD_WSCALE = 1024.0f;   // the packed forward kernels are 2^10 * W: |w| < 64 stays inside fp16, a weight of 1e-4 keeps a normal low part
 AZR_HOOK_FLAG g_fuse_bwd = true;
+#ifndef WG5_NC
+#define WG5_NC 4   // co tiles per wave of t_wgrad_g5 (2: half the split-K partials but 20 fragment reads per 54 MFMAs instead of 28 per 108 — 86.9 us against 61.2)
+#endif
 AZR_HOOK_FLAG g_wgrad_g5 = true;    // t_wgrad_g5 (k-step = a board row of five boards); AZR_TRAIN_WGRAD=rs: t_wgrad_rs (rows in memory order), the older formulation
 AZR_HOOK_FLAG g_conv_q = true;       // t_conv_q for batches of up to 128 records (AZR_TRAIN_CONVQ=0: t_conv_rs at every size)
 AZR_HOOK_FLAG g_fuse_apply = true;   // t_conv_rs<.., PRO>: the normalise kernels (t_bn_apply / t_bn_bwd_apply) computed in the consuming conv's staging path (AZR_TRAIN_FUSE_APPLY=0: separate kernels; same bits)   // t_conv_rs<2, 2, 1>: shortcut add + BN-backward stage 1 in the backward-data conv's epilogue (AZR_TRAIN_FUSE=0: separate kernels)
@@ -2298,7 +2283,8 @@ static void launch_wgrad(TrainCtx* c, hipStream_t st, const Parts& apP, const Pa
         return;
     }
 #endif
-    hipLaunchKernelGGL(t_wgrad_g5, dim3(64 * c->wg_slices), dim3(64), Wg5::LDS_BYTES, st, apP, dyP, c->wpart, M / NPOS, c->wg_slices, c->wg_bps);
+    hipLaunchKernelGGL(t_wgrad_g5<WG5_NC>, dim3(Wg5<WG5_NC>::BLOCKS_PER_SLICE * c->wg_slices), dim3(64), Wg5<WG5_NC>::LDS_BYTES, st, apP, dyP, c->wpart, M / NPOS,
+                       c->wg_slices, c->wg_bps);
 }
 
 int ctx_ensure(azr_engine* h, int BS)
@@ -2317,7 +2303,7 @@ int ctx_ensure(azr_engine* h, int BS)
 #ifdef AZR_TEST_HOOKS
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(t_wgrad_rs), hipFuncAttributeMaxDynamicSharedMemorySize, Wg::LDS_BYTES));
 #endif
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(t_wgrad_g5), hipFuncAttributeMaxDynamicSharedMemorySize, Wg5::LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(t_wgrad_g5<WG5_NC>), hipFuncAttributeMaxDynamicSharedMemorySize, Wg5<WG5_NC>::LDS_BYTES));
     // a different batch size rebuilds the activation slabs but keeps the optimiser state
     std::vector<float> keep_m, keep_v;
     long keep_step = 0;
@@ -2353,8 +2339,12 @@ int ctx_ensure(azr_engine* h, int BS)
     {
         // (small batches — a rank's share of a data-parallel minibatch: 8-board slices, so that 64 records are 512 one-wave blocks)
         int bps = (BS <= 128 && BS % 8 == 0) ? 8 : 16 * std::max(1, BS / 256);
-        // t_wgrad_g5: whole groups of 5 boards, about 16 slices (x 64 one-wave blocks = the chip's 1024 SIMDs): 512 records = 15 slices of 35
-        if (g_wgrad_g5) bps = std::max(Wg5::GB, ((BS + 15) / 16 + Wg5::GB - 1) / Wg5::GB * Wg5::GB);
+        // t_wgrad_g5: whole groups of 5 boards, as many slices as make the chip's 1024 SIMDs one block each
+        if (g_wgrad_g5) {
+            using W = Wg5<WG5_NC>;
+            const int want = 1024 / W::BLOCKS_PER_SLICE;
+            bps = std::max(W::GB, ((BS + want - 1) / want + W::GB - 1) / W::GB * W::GB);
+        }
         c->wg_slices = (BS + bps - 1) / bps;
         c->wg_rows = bps * NPOS;
         c->wg_bps = bps;
