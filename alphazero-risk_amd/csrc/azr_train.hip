@@ -1298,7 +1298,8 @@ struct Wg5 {
     static constexpr int GST = NC == 4 ? 160 : 96;
     __host__ __device__ static constexpr int grow(int r) { return r * GST + (r >> 3) * 128; }
     static constexpr int GPB = KR * GST + (KR / 8) * 128;
-    static constexpr int LDS_BYTES = 2 * APB + 2 * GPB;               // A part 0 | A part 1 | dY part 0 | dY part 1
+    static constexpr int LDS_BYTES = 2 * APB + 2 * GPB;               // one wave's tile: A part 0 | A part 1 | dY part 0 | dY part 1
+    static constexpr int LDS_BLOCK = 4 * LDS_BYTES > 2 * 9 * NC * 1024 ? 4 * LDS_BYTES : 2 * 9 * NC * 1024;   // four waves' tiles, or two accumulator sets in the closing sum
     static constexpr int COW = 16 * NC;                                // output channels per wave
     static constexpr int BLOCKS_PER_SLICE = 16 * (NF / COW);
     // the memory operations of a k-step, in dependence order: tile stores (GU dY units x 2 parts, 2 A units), global loads (the same
@@ -1334,16 +1335,24 @@ __device__ __forceinline__ void g5_tap(const s16x8 (&a)[2], const s16x8 (&gf)[2]
         acc[T][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, gf[0][c]), acc[T][c], 0, 0, 0);
 }
 
+// A block is FOUR waves = four slices of one (ci tile, co range): each wave runs its slice alone (private tile, no barrier in the loop),
+// and the four accumulator sets are summed through LDS before anything is written — a quarter of the split-K partials leave the chip and
+// come back into the slice sum (512 records: 4 instead of 15 per weight; t_sum_slices_fin 10.6 -> 6.4 us, the kernel itself unchanged:
+// the two rounds through LDS cost what the smaller write saves).  Block id -> (quad of slices, rest): the blocks of a quad are NQ apart,
+// i.e. on the same two XCDs, whose L2s then hold that quad's dY.
 template <int NC>
-__global__ __launch_bounds__(64, 1) void t_wgrad_g5(Parts A, Parts G, float* __restrict__ out, int boards, int NS, int boards_per_slice)
+__global__ __launch_bounds__(256, 1) void t_wgrad_g5(Parts A, Parts G, float* __restrict__ out, int boards, int NS, int boards_per_slice)
 {
     using W = Wg5<NC>;
-    extern __shared__ __attribute__((aligned(16))) uint8_t wg_lds[];
-    const int lane = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) uint8_t wg_lds_all[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // (uniform by construction: say so, or every buffer load gets a waterfall loop around its descriptor)
+    uint8_t* wg_lds = wg_lds_all + wave * W::LDS_BYTES;
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
-    const int slice = blockIdx.x % NS, rest = blockIdx.x / NS, cit = rest & 15, wq = rest >> 4;   // wq = which COW output channels
+    const int NQ = (NS + 3) / 4;
+    const int quad = blockIdx.x % NQ, rest = blockIdx.x / NQ, cit = rest & 15, wq = rest >> 4;   // wq = which COW output channels
+    const int slice = quad * 4 + wave;
     const int bbeg = slice * boards_per_slice, bend = min(boards, bbeg + boards_per_slice);
-    const int S = W::ROWS_Y * ((bend - bbeg + W::GB - 1) / W::GB);   // k-steps of the slice
+    const int S = slice < NS ? W::ROWS_Y * ((bend - bbeg + W::GB - 1) / W::GB) : 0;   // k-steps of the slice (a quad past the last slice: none)
 
     if (lane < 2 * (W::AST / 4))   // zero rows of the two A parts
         reinterpret_cast<uint32_t*>(wg_lds + (lane / (W::AST / 4)) * W::APB + W::arow(32))[lane % (W::AST / 4)] = 0u;
@@ -1479,14 +1488,41 @@ __global__ __launch_bounds__(64, 1) void t_wgrad_g5(Parts A, Parts G, float* __r
         if (s + 5 < S) kstep(IC(5), s + 5);
     }
 #undef IC
-    float* o = out + (size_t)slice * KC * NF;
+    // (w0 + w2) + (w1 + w3): two rounds through LDS (the tiles are dead behind the first barrier), 16 bytes per lane and accumulator tile
+    f32x4* red = reinterpret_cast<f32x4*>(wg_lds_all) + lane;
+    constexpr int TILES = 9 * NC;
+    __syncthreads();
+    if (wave >= 2) {
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+            for (int c = 0; c < NC; c++) red[((wave - 2) * TILES + t * NC + c) * 64] = acc[t][c];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+            for (int c = 0; c < NC; c++) acc[t][c] += red[(wave * TILES + t * NC + c) * 64];
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+            for (int c = 0; c < NC; c++) red[(t * NC + c) * 64] = acc[t][c];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    float* o = out + (size_t)quad * KC * NF;
 #pragma unroll
     for (int t = 0; t < 9; t++)
 #pragma unroll
-        for (int c = 0; c < NC; c++)
+        for (int c = 0; c < NC; c++) {
+            const f32x4 v = acc[t][c] + red[(t * NC + c) * 64];
 #pragma unroll
-            for (int e = 0; e < 4; e++)
-                o[(size_t)(t * NF + cit * 16 + 4 * g + e) * NF + wq * W::COW + c * 16 + i16] = acc[t][c][e];
+            for (int e = 0; e < 4; e++) o[(size_t)(t * NF + cit * 16 + 4 * g + e) * NF + wq * W::COW + c * 16 + i16] = v[e];
+        }
 }
 
 // out[i] = sum_z part[z][i]
@@ -2206,6 +2242,7 @@ struct TrainCtx {
     int BS = 0, blocks = 0, M = 0, L = 0, R = 0, nz = 0, kchunk = 0;
     int wg_slices = 0, wg_rows = 0;          // weight gradient: slices (split-K units of whole boards) and rows per slice
     int wg_bps = 0;                          // ... boards per slice
+    int wg_parts = 0;                        // ... split-K partials that reach memory (t_wgrad_g5: one per four slices, summed in the block)
     size_t count = 0;
     long step = 0;
     float *g = nullptr, *m = nullptr, *v = nullptr;
@@ -2283,7 +2320,7 @@ static void launch_wgrad(TrainCtx* c, hipStream_t st, const Parts& apP, const Pa
         return;
     }
 #endif
-    hipLaunchKernelGGL(t_wgrad_g5<WG5_NC>, dim3(Wg5<WG5_NC>::BLOCKS_PER_SLICE * c->wg_slices), dim3(64), Wg5<WG5_NC>::LDS_BYTES, st, apP, dyP, c->wpart, M / NPOS,
+    hipLaunchKernelGGL(t_wgrad_g5<WG5_NC>, dim3(Wg5<WG5_NC>::BLOCKS_PER_SLICE * c->wg_parts), dim3(256), Wg5<WG5_NC>::LDS_BLOCK, st, apP, dyP, c->wpart, M / NPOS,
                        c->wg_slices, c->wg_bps);
 }
 
@@ -2303,7 +2340,7 @@ int ctx_ensure(azr_engine* h, int BS)
 #ifdef AZR_TEST_HOOKS
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(t_wgrad_rs), hipFuncAttributeMaxDynamicSharedMemorySize, Wg::LDS_BYTES));
 #endif
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(t_wgrad_g5<WG5_NC>), hipFuncAttributeMaxDynamicSharedMemorySize, Wg5<WG5_NC>::LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(t_wgrad_g5<WG5_NC>), hipFuncAttributeMaxDynamicSharedMemorySize, Wg5<WG5_NC>::LDS_BLOCK));
     // a different batch size rebuilds the activation slabs but keeps the optimiser state
     std::vector<float> keep_m, keep_v;
     long keep_step = 0;
@@ -2348,6 +2385,7 @@ int ctx_ensure(azr_engine* h, int BS)
         c->wg_slices = (BS + bps - 1) / bps;
         c->wg_rows = bps * NPOS;
         c->wg_bps = bps;
+        c->wg_parts = g_wgrad_g5 ? (c->wg_slices + 3) / 4 : c->wg_slices;
     }
     TRY(dalloc(h, c, &c->wpart, (size_t)std::max(c->nz, c->wg_slices) * KC * NF));
     // bf16 parts of the post-activations: the two leading parts are kept PER LAYER (the weight-gradient GEMM of the backward
@@ -2614,11 +2652,11 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
             TRY(dp_allreduce(h, c, c->red, (size_t)2 * NF, 1));
         }
         if (pending_sum && !dp && fused_parts) {
-            hipLaunchKernelGGL(t_sum_slices_fin, dim3(8 + (unsigned)((wn + 1023) / 1024)), dim3(1024), 0, st, c->wpart, c->wg_slices, wn, pending_sum, c->part,
+            hipLaunchKernelGGL(t_sum_slices_fin, dim3(8 + (unsigned)((wn + 1023) / 1024)), dim3(1024), 0, st, c->wpart, c->wg_parts, wn, pending_sum, c->part,
                                Rl, gbn, c->sums, gscale);
             pending_sum = nullptr;
         } else {
-            if (pending_sum) { hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, c->wg_slices, wn, pending_sum); pending_sum = nullptr; }
+            if (pending_sum) { hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, c->wg_parts, wn, pending_sum); pending_sum = nullptr; }
             hipLaunchKernelGGL((t_bn_bwd_finalize<false>), dim3(8), dim3(1024), 0, st, dp ? c->red : c->part, dp ? 1 : Rl, gbn, c->sums, gscale);
         }
         float* dIn = second ? c->DT : c->G;
@@ -2661,7 +2699,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
             HIPCHK(h, hipEventRecord(c->ev_conv[q], st));
             HIPCHK(h, hipStreamWaitEvent(c->side, c->ev_conv[q], 0));
             launch_wgrad(c, c->side, apP, dyP, M);
-            hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, c->side, c->wpart, c->wg_slices, wn, Gl(l));
+            hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, c->side, c->wpart, c->wg_parts, wn, Gl(l));
             HIPCHK(h, hipEventRecord(c->ev_wg[q], c->side));
             side_used |= 1 << q;
             continue;
@@ -2679,7 +2717,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         } else
 #endif
         gemm<true, false, 128, 1, 0>(st, Al(l - 1), KC, c->dY, NF, c->wpart, NF, KC, NF, M, c->nz, c->kchunk, wn);
-        hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, sb ? c->wg_slices : c->nz, wn, Gl(l));
+        hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, sb ? c->wg_parts : c->nz, wn, Gl(l));
         // d(input) = transposed conv of dY with W: the same implicit GEMM with negated taps and W read as [tap][co] x [ci]
         fused_parts = 0;
 #ifdef AZR_TEST_HOOKS
@@ -2696,7 +2734,7 @@ int train_step(azr_engine* h, TrainCtx* c, float* d_acc)
         gemm<false, true, 64, 2, 3>(st, c->dY, KC, Wl(l), NF, dIn, NF, M, NF, KC);
         if (!second) hipLaunchKernelGGL(t_add, dim3(g4), dim3(256), 0, st, dIn, c->DS, act / 4);  // + shortcut gradient
     }
-    if (pending_sum) hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, c->wg_slices, wn, pending_sum);
+    if (pending_sum) hipLaunchKernelGGL(t_sum_slices, grid1(wn, 256), dim3(256), 0, st, c->wpart, c->wg_parts, wn, pending_sum);
     // the weight-gradient branch joins: the stem below reuses its split-K buffer, and the gradient vector is complete behind it
     for (int q = 0; q < 2; q++) if ((side_used >> q) & 1) HIPCHK(h, hipStreamWaitEvent(st, c->ev_wg[q], 0));
     {   // stem: parameters only
