@@ -822,6 +822,9 @@ __global__ __launch_bounds__(256, 1) void t_conv_q(Parts A, Parts Bp, float* __r
     __shared__ uint8_t taprow[9 * ZR];
     __shared__ __attribute__((aligned(16))) float ptab[PRO ? 5 * NF : 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    // (wave enters the weight loads' scalar offset and the compiler cannot prove it wave-uniform: each of those loads sits in a waterfall loop.
+    //  Saying so with readfirstlane removes the loops and 32 VGPRs — and measures SLOWER at 64 records: 43.7 / 25.4 us against 34.6 / 20.2 for
+    //  the backward / forward conv; the loops pace the loads between the MFMAs better than the scheduler does without them.  Left as it is.)
     const int board = blockIdx.x >> 2, cq = blockIdx.x & 3, m0 = board * NPOS;
     (void)boards;
 
