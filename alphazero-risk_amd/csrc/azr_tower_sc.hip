@@ -30,8 +30,9 @@
 // path is the bound and the touches double its traffic.
 // Exchange images are double-buffered by layer parity: to overwrite parity p a workgroup must have finished layer L + 1, which
 // needed every partner's layer-L + 1 slice, which they produced after reading layer L — no reader can be behind.  All workgroups of
-// a launch must be co-resident: <= 256 workgroups of 64 KB LDS and <= 256 VGPRs (two fit on a CU: two networks of an arena side by
-// side stay resident).  Block ids are laid out so that a pair's workgroups are 8 ids apart (same XCD under round-robin dispatch:
+// a launch must be co-resident: <= 256 workgroups of 64 KB LDS and <= 256 VGPRs (two fit on a CU, at 0.66 ms instead of 0.33: the two networks
+// of an arena, side by side, take this kernel only while their workgroups have a CU each — n_other below).
+// Block ids are laid out so that a pair's workgroups are 8 ids apart (same XCD under round-robin dispatch:
 // speed only).  Arithmetic = k_tower_sb<2>'s: same packed weights, row order, skipped (tile, tap) pairs, k order, fp32 epilogue and
 // RNE points — bit-identical results (tests/test_gpu_net.py::test_tile_shapes_agree_bit_for_bit).
 #include <stdlib.h>
